@@ -1,0 +1,135 @@
+/*
+ * hip_raytracer.h - C ABI of the MI355X (gfx950) backend for the reference's IRaytracer hot path.
+ *
+ * This is the drop-in boundary: a `HIPRaytracer : IRaytracer` (C++: opencl-raytracer_amd/host/HIPRaytracer.hpp,
+ * Python: opencl-raytracer_amd/hip_raytracer.py) replaces the reference's `OpenCLRaytracer` and calls only
+ * these entry points. Plain pointers and sizes; no C++/torch/HIP types in any signature.
+ *
+ * Reference interfaces replaced (citations into the reference tree):
+ *   rt_create          <- OpenCLRaytracer::OpenCLRaytracer(objects, lights, rays, MAX_BOUNCES)
+ *                         OpenCLRaytracer.cpp:13-74 (AoS conversion :16-33, buffers :47-50, program build :53-59,
+ *                         kernel args :62-68, uploads :70-73)
+ *   rt_render          <- OpenCLRaytracer::Render()  OpenCLRaytracer.cpp:80-105 (enqueue_1d_range_kernel :89-91,
+ *                         blocking enqueue_read_buffer :94, returns the object-owned host buffer :104);
+ *                         declared by IRaytracer::Render()  IRaytracer.hpp:13
+ *   rt_render_device   <- the same launch without the read-back (device-resident framebuffer; used for
+ *                         multi-GPU gathers and for timing with inputs/outputs resident in HBM)
+ *   rt_destroy         <- OpenCLRaytracer::~OpenCLRaytracer()  OpenCLRaytracer.cpp:76-78
+ *   rt_set_camera      <- main()'s primary-ray loop  OpenCL-Raytracer.cpp:18-26,68-72 (rays regenerated in-kernel)
+ *   kernel selector    <- `__kernel hittest`  hittest_kernel.cl:54, `__kernel shade`  shade_kernel.cl:180,
+ *                         `__kernel shade_and_reflect`  shade_and_reflect_kernel.cl:244
+ *
+ * Record layouts are the reference's device structs, byte for byte (shade_and_reflect_kernel.cl:1-29,
+ * OpenCLRaytracer.hpp:25-58): ObjectData 320 B, Light 64 B, Ray 32 B, pixel float4 16 B. See rt_records.h.
+ *
+ * Error behaviour: the reference has no error codes (Boost.Compute throws). Every function here returns
+ * RT_OK (0) or a negative rt_status and records a message retrievable with rt_last_error(); nothing throws
+ * across the boundary. There is no CPU fallback: without a usable HIP device rt_create fails with
+ * RT_ERR_NO_DEVICE.
+ *
+ * Threading: like the reference (single in-order queue, OpenCLRaytracer.cpp:44) a context is not
+ * re-entrant; use one context per thread / per GPU.
+ */
+#ifndef HIP_RAYTRACER_H
+#define HIP_RAYTRACER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_ABI_VERSION 1
+
+typedef struct rt_context rt_context;
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID_ARGUMENT = -1,
+    RT_ERR_NO_DEVICE = -2,
+    RT_ERR_OUT_OF_MEMORY = -3,
+    RT_ERR_HIP = -4,
+    RT_ERR_STATE = -5
+} rt_status;
+
+typedef enum rt_kernel {
+    RT_KERNEL_HITTEST = 0,           /* nearest t per ray          (hittest_kernel.cl:54)            */
+    RT_KERNEL_SHADE = 1,             /* direct lighting, summed    (shade_kernel.cl:180)             */
+    RT_KERNEL_SHADE_AND_REFLECT = 2  /* + iterative reflection     (shade_and_reflect_kernel.cl:244) */
+} rt_kernel;
+
+/* rt_create flags */
+#define RT_FLAG_UNFUSED   0x1u /* arithmetic of an OpenCL device WITHOUT fma contraction (x86 baseline); default
+                                  is the contraction the OpenCL front-end marks (llvm.fmuladd -> fma)          */
+#define RT_FLAG_LITERAL   0x2u /* trace every ray the reference traces (no exact eliminations: any-hit shadow
+                                  early-out, backward light scan, dead reflection ray). Results are identical */
+#define RT_FLAG_NO_RAYGEN 0x4u /* never replace an uploaded pinhole ray grid by in-kernel generation            */
+
+typedef struct rt_stats_t {
+    uint64_t rays_traced;     /* rays this backend actually issued in the last counted render (R_act)          */
+    uint64_t rays_reference;  /* rays the reference semantics trace for the same frame (R_ref)                 */
+    uint64_t hit_pixels;      /* work-items whose primary ray hit something                                    */
+    float    last_kernel_ms;  /* device time of the last render's kernel(s), HIP events on the render stream   */
+    uint32_t pinhole;         /* 1 if primary rays are generated in-kernel                                     */
+    uint32_t width, height;   /* pinhole grid (0 when rays come from the uploaded buffer)                      */
+    uint64_t local_rays;      /* work-items this context renders (after rt_set_shard)                          */
+} rt_stats_t;
+
+/* Build a raytracer for one GPU.
+ *   objs   : n_objs  x 320-byte ObjectData records (may be NULL when n_objs == 0)
+ *   lights : n_lights x 64-byte Light records      (may be NULL when n_lights == 0)
+ *   rays   : n_rays  x 32-byte Ray records in work-item order, or NULL when rt_set_camera() will
+ *            describe an n_rays = width*height pinhole grid
+ *   max_bounces : MAX_BOUNCES of shade_and_reflect (ignored by the other kernels, as in the reference)
+ *   device : HIP device ordinal
+ * Host buffers are copied; the caller may free them after the call returns. */
+int rt_create(rt_context** ctx, const void* objs, uint32_t n_objs, const void* lights, uint32_t n_lights,
+              const void* rays, uint64_t n_rays, uint32_t max_bounces, int kernel, int device, uint32_t flags);
+
+/* Primary rays = the reference's pinhole grid, generated in-kernel (bit-exact):
+ * start (0,0,0,1), direction (i - W/2, (H - j) - H/2, z, 0) for work-item j*W + i. width*height must equal n_rays. */
+int rt_set_camera(rt_context* ctx, uint32_t width, uint32_t height, float z);
+
+/* Multi-GPU partition: work-items are cut into tiles of `tile_rays` consecutive rays (a row-tile is
+ * tile_rows*width rays); tile j belongs to rank j % world. After this call the context renders only its
+ * own tiles, packed back to back in its output buffer (rt_local_rays() work-items). */
+int rt_set_shard(rt_context* ctx, uint64_t tile_rays, uint32_t rank, uint32_t world);
+uint64_t rt_local_rays(const rt_context* ctx);
+
+/* Synchronous render into a context-owned host buffer, like IRaytracer::Render():
+ *   kernels 1,2: rt_local_rays() x float4; RGB in [0..2]; misses are (0,0,0,1) (the reference's upload-time
+ *                background, OpenCLRaytracer.cpp:32), hit pixels have w = 1
+ *   kernel 0   : rt_local_rays() x float; misses are 3.402823466e+38f
+ * The buffer is overwritten by the next call and freed by rt_destroy. */
+int rt_render(rt_context* ctx, const float** out);
+
+/* Asynchronous render into caller-provided DEVICE memory (same element layout) on a caller-provided HIP stream
+ * (hipStream_t passed as void*; NULL = the context's own stream). No host synchronisation. */
+int rt_render_device(rt_context* ctx, void* d_out, void* hip_stream);
+
+/* Optional per-work-item primary-hit record of the NEXT render: t (float) and winning object index
+ * (int32, -1 on a miss) into caller-provided DEVICE buffers of rt_local_rays() elements (either may be NULL). */
+int rt_set_aux_device(rt_context* ctx, void* d_hit_t, void* d_hit_index);
+/* Host-side convenience: render once and copy t / index to host arrays (either may be NULL). */
+int rt_render_aux(rt_context* ctx, float* hit_t, int32_t* hit_index);
+
+/* Counted render (untimed instrumentation pass): fills rays_traced / rays_reference / hit_pixels. */
+int rt_count_rays(rt_context* ctx);
+int rt_get_stats(rt_context* ctx, rt_stats_t* stats);
+
+/* Device-time bookkeeping: every render records a HIP event pair around its kernel(s) on the stream it was
+ * launched on (up to 256 launches are kept). rt_timing_summary waits for them and returns the summed device
+ * time and the number of launches since rt_timing_reset. */
+int rt_timing_reset(rt_context* ctx);
+int rt_timing_summary(rt_context* ctx, double* sum_ms, uint32_t* launches);
+
+void rt_destroy(rt_context* ctx);
+/* Message of the last failure on this context (ctx may be NULL for a failed rt_create). */
+const char* rt_last_error(const rt_context* ctx);
+int rt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIP_RAYTRACER_H */

@@ -1,0 +1,471 @@
+// rt_api.cpp - the C ABI of include/hip_raytracer.h: context life cycle, scene re-pack + upload, render.
+//
+// Plays the role of the reference's OpenCLRaytracer ctor/Render()/dtor (OpenCLRaytracer.cpp:13-105) for one
+// MI355X. There is deliberately no CPU path here: every failure to reach the GPU is an error.
+#include "hip_raytracer.h"
+#include "rt_records.h"
+#include "rt_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+constexpr uint32_t kTimingSlots = 256;
+
+}  // namespace
+
+struct rt_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t flags = 0;
+    int kernel = 2;
+    uint32_t n_objs = 0, n_lights = 0, max_bounces = 0;
+    uint64_t n_rays = 0;
+
+    rt::HotObject* d_hot = nullptr;
+    rt::ColdObject* d_cold = nullptr;
+    rt::LightRec* d_lights = nullptr;
+    float4* d_rays = nullptr;
+    bool have_rays = false;  // ray buffer uploaded
+    bool dir_w_zero = true;
+
+    bool pinhole = false;
+    uint32_t width = 0, height = 0;
+    float z = 0.f;
+
+    uint64_t tile_rays = 0;
+    uint32_t rank = 0, world = 1;
+    uint64_t n_local = 0;
+
+    void* d_out = nullptr;  // context-owned device framebuffer
+    size_t d_out_bytes = 0;
+    void* h_out = nullptr;  // context-owned pinned host framebuffer (Render()'s return value)
+    size_t h_out_bytes = 0;
+
+    float* aux_t = nullptr;  // caller-owned device buffers for the next render
+    int32_t* aux_index = nullptr;
+
+    rt::Counters* d_counters = nullptr;
+    rt::Counters counters = {0, 0, 0};
+
+    hipEvent_t ev_begin[kTimingSlots];
+    hipEvent_t ev_end[kTimingSlots];
+    uint32_t ev_count = 0;   // launches recorded since the last rt_timing_reset
+    bool ev_created = false;
+    float last_ms = 0.f;
+
+    std::string error;
+};
+
+namespace {
+
+int fail(rt_context* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->error = msg;
+    else g_create_error = msg;
+    return code;
+}
+
+int fail_hip(rt_context* ctx, hipError_t e, const char* what) {
+    return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define RT_HIP(ctx, call)                                           \
+    do {                                                            \
+        hipError_t e_ = (call);                                     \
+        if (e_ != hipSuccess) return fail_hip((ctx), e_, #call);    \
+    } while (0)
+
+size_t elem_bytes(const rt_context* c) { return c->kernel == RT_KERNEL_HITTEST ? sizeof(float) : 4 * sizeof(float); }
+
+uint64_t local_count(uint64_t n_rays, uint64_t tile_rays, uint32_t rank, uint32_t world) {
+    if (world <= 1) return n_rays;
+    const uint64_t tiles = (n_rays + tile_rays - 1) / tile_rays;
+    const uint64_t mine = tiles / world + ((tiles % world) > rank ? 1 : 0);
+    return mine * tile_rays;  // the last tile may be ragged: its padding work-items write background
+}
+
+// ObjectData[] (320 B AoS, as uploaded by the reference) -> hot traversal stream + cold shading records
+void repack_objects(const rt_object_data* objs, uint32_t n, std::vector<rt::HotObject>& hot,
+                    std::vector<rt::ColdObject>& cold) {
+    hot.resize(n);
+    cold.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        const rt_object_data& o = objs[i];
+        const float* m = o.mvInverse;
+        rt::HotObject& h = hot[i];
+        h.row0 = make_float4(m[0], m[4], m[8], m[12]);
+        h.row1 = make_float4(m[1], m[5], m[9], m[13]);
+        h.row2 = make_float4(m[2], m[6], m[10], m[14]);
+        h.type = o.type;
+        h.pad[0] = h.pad[1] = h.pad[2] = 0;
+        rt::ColdObject& c = cold[i];
+        std::memcpy(c.mv, o.mv, sizeof(c.mv));
+        c.inv_row3 = make_float4(m[3], m[7], m[11], m[15]);
+        c.amb_absorb = make_float4(o.mat.ambient[0], o.mat.ambient[1], o.mat.ambient[2], o.mat.absorption);
+        c.dif_shine = make_float4(o.mat.diffuse[0], o.mat.diffuse[1], o.mat.diffuse[2], o.mat.shininess);
+        float type_bits;
+        std::memcpy(&type_bits, &o.type, 4);
+        c.spec_type = make_float4(o.mat.specular[0], o.mat.specular[1], o.mat.specular[2], type_bits);
+    }
+}
+
+// Is the uploaded ray list bit-for-bit the reference's pinhole grid (OpenCL-Raytracer.cpp:18-26,68-72)?
+bool detect_pinhole(const rt_ray* rays, uint64_t n, uint32_t& W, uint32_t& H, float& z) {
+    if (n == 0 || n > 0xffffffffull) return false;
+    const float y0 = rays[0].direction[1];
+    uint64_t w = n;
+    for (uint64_t i = 1; i < n; ++i) {
+        if (rays[i].direction[1] != y0) { w = i; break; }
+    }
+    if (w == 0 || n % w != 0) return false;
+    const uint64_t h = n / w;
+    if (w > 0x1000000ull || h > 0x1000000ull) return false;  // exact integer -> float conversion range
+    const float zz = rays[0].direction[2];
+    const float half_w = (float)w / 2.0f, half_h = (float)h / 2.0f, hf = (float)h;
+    for (uint64_t j = 0; j < h; ++j) {
+        const float dy = (hf - (float)j) - half_h;
+        const rt_ray* row = rays + j * w;
+        for (uint64_t i = 0; i < w; ++i) {
+            const rt_ray& r = row[i];
+            const float expect[8] = {0.f, 0.f, 0.f, 1.f, (float)i - half_w, dy, zz, 0.f};
+            if (std::memcmp(&r, expect, sizeof(expect)) != 0) return false;
+        }
+    }
+    W = (uint32_t)w;
+    H = (uint32_t)h;
+    z = zz;
+    return true;
+}
+
+int ensure_out(rt_context* c) {
+    const size_t need = (size_t)c->n_local * elem_bytes(c);
+    if (need > c->d_out_bytes) {
+        if (c->d_out) (void)hipFree(c->d_out);
+        c->d_out = nullptr;
+        c->d_out_bytes = 0;
+        RT_HIP(c, hipMalloc(&c->d_out, need ? need : 16));
+        c->d_out_bytes = need;
+    }
+    return RT_OK;
+}
+
+int ensure_host_out(rt_context* c) {
+    const size_t need = (size_t)c->n_local * elem_bytes(c);
+    if (need > c->h_out_bytes) {
+        if (c->h_out) (void)hipHostFree(c->h_out);
+        c->h_out = nullptr;
+        c->h_out_bytes = 0;
+        RT_HIP(c, hipHostMalloc(&c->h_out, need ? need : 16, hipHostMallocDefault));
+        c->h_out_bytes = need;
+    }
+    return RT_OK;
+}
+
+int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
+    if (c->n_local == 0) {  // empty launch: nothing to render, nothing to time
+        if (count) c->counters = rt::Counters{0, 0, 0};
+        c->aux_t = nullptr;
+        c->aux_index = nullptr;
+        return RT_OK;
+    }
+    if (!c->pinhole && !c->have_rays)
+        return fail(c, RT_ERR_STATE, "no primary rays: rt_create got rays == NULL and rt_set_camera was not called");
+    rt::RenderParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.scene.hot = c->d_hot;
+    p.scene.cold = c->d_cold;
+    p.scene.lights = c->d_lights;
+    p.scene.n_objs = c->n_objs;
+    p.scene.n_lights = c->n_lights;
+    p.scene.literal = (c->flags & RT_FLAG_LITERAL) ? 1u : 0u;
+    p.rays = c->pinhole ? nullptr : c->d_rays;
+    p.n_rays = c->n_rays;
+    p.n_local = c->n_local;
+    p.tile_rays = c->tile_rays ? c->tile_rays : 1;
+    p.rank = c->rank;
+    p.world = c->world;
+    p.pinhole = c->pinhole ? 1u : 0u;
+    p.width = c->width ? c->width : 1;
+    p.half_w = (float)c->width / 2.0f;
+    p.half_h = (float)c->height / 2.0f;
+    p.height_f = (float)c->height;
+    p.z = c->z;
+    p.dir_w_zero = (c->pinhole || c->dir_w_zero) ? 1u : 0u;
+    p.max_bounces = c->max_bounces;
+    p.out = d_out;
+    p.aux_t = c->aux_t;
+    p.aux_index = c->aux_index;
+    p.counters = c->d_counters;
+
+    RT_HIP(c, hipSetDevice(c->device));
+    if (count) RT_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters), stream));
+    const uint32_t slot = c->ev_count % kTimingSlots;
+    RT_HIP(c, hipEventRecord(c->ev_begin[slot], stream));
+    const hipError_t e = rt::launch_render(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, stream);
+    if (e != hipSuccess) return fail_hip(c, e, "kernel launch");
+    RT_HIP(c, hipEventRecord(c->ev_end[slot], stream));
+    c->ev_count += 1;
+    // aux buffers apply to one render only
+    c->aux_t = nullptr;
+    c->aux_index = nullptr;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char* rt_last_error(const rt_context* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const void* lights, uint32_t n_lights,
+              const void* rays, uint64_t n_rays, uint32_t max_bounces, int kernel, int device, uint32_t flags) {
+    g_create_error.clear();
+    if (!out_ctx) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "ctx is NULL");
+    *out_ctx = nullptr;
+    if (kernel < 0 || kernel > 2) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "kernel must be 0, 1 or 2");
+    if ((n_objs && !objs) || (n_lights && !lights))
+        return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "objs/lights is NULL with a non-zero count");
+    if (flags & ~(RT_FLAG_UNFUSED | RT_FLAG_LITERAL | RT_FLAG_NO_RAYGEN))
+        return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "unknown flag bits");
+
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device available (this backend has no CPU fallback)");
+    if (device < 0 || device >= n_dev) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+
+    rt_context* c = new (std::nothrow) rt_context();
+    if (!c) return fail(nullptr, RT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    c->device = device;
+    c->flags = flags;
+    c->kernel = kernel;
+    c->n_objs = n_objs;
+    c->n_lights = n_lights;
+    c->n_rays = n_rays;
+    c->n_local = n_rays;
+    c->max_bounces = max_bounces;
+
+    int rc = RT_OK;
+    auto bail = [&](int code) {
+        g_create_error = c->error;
+        rt_destroy(c);
+        return code;
+    };
+#define RT_TRY(call)                                      \
+    do {                                                  \
+        hipError_t e2_ = (call);                          \
+        if (e2_ != hipSuccess) { rc = fail_hip(c, e2_, #call); return bail(rc); } \
+    } while (0)
+
+    RT_TRY(hipSetDevice(device));
+    RT_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (uint32_t i = 0; i < kTimingSlots; ++i) {
+        RT_TRY(hipEventCreate(&c->ev_begin[i]));
+        RT_TRY(hipEventCreate(&c->ev_end[i]));
+    }
+    c->ev_created = true;
+    RT_TRY(hipMalloc((void**)&c->d_counters, sizeof(rt::Counters)));
+
+    {
+        std::vector<rt::HotObject> hot;
+        std::vector<rt::ColdObject> cold;
+        repack_objects(static_cast<const rt_object_data*>(objs), n_objs, hot, cold);
+        // one spare record keeps the arrays non-null for n_objs == 0
+        RT_TRY(hipMalloc((void**)&c->d_hot, sizeof(rt::HotObject) * (size_t)(n_objs + 1)));
+        RT_TRY(hipMalloc((void**)&c->d_cold, sizeof(rt::ColdObject) * (size_t)(n_objs + 1)));
+        if (n_objs) {
+            RT_TRY(hipMemcpy(c->d_hot, hot.data(), sizeof(rt::HotObject) * n_objs, hipMemcpyHostToDevice));
+            RT_TRY(hipMemcpy(c->d_cold, cold.data(), sizeof(rt::ColdObject) * n_objs, hipMemcpyHostToDevice));
+        }
+    }
+    RT_TRY(hipMalloc((void**)&c->d_lights, sizeof(rt::LightRec) * (size_t)(n_lights + 1)));
+    if (n_lights) RT_TRY(hipMemcpy(c->d_lights, lights, sizeof(rt::LightRec) * n_lights, hipMemcpyHostToDevice));
+
+    if (rays && n_rays) {
+        const rt_ray* r = static_cast<const rt_ray*>(rays);
+        uint32_t W = 0, H = 0;
+        float z = 0.f;
+        if (!(flags & RT_FLAG_NO_RAYGEN) && detect_pinhole(r, n_rays, W, H, z)) {
+            c->pinhole = true;
+            c->width = W;
+            c->height = H;
+            c->z = z;
+        } else {
+            bool w0 = true;
+            for (uint64_t i = 0; i < n_rays && w0; ++i) w0 = (r[i].direction[3] == 0.0f);
+            c->dir_w_zero = w0;
+            RT_TRY(hipMalloc((void**)&c->d_rays, sizeof(rt_ray) * (size_t)n_rays));
+            RT_TRY(hipMemcpy(c->d_rays, rays, sizeof(rt_ray) * (size_t)n_rays, hipMemcpyHostToDevice));
+            c->have_rays = true;
+        }
+    }
+#undef RT_TRY
+    *out_ctx = c;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_context* c, uint32_t width, uint32_t height, float z) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (width == 0 || height == 0 || (uint64_t)width * height != c->n_rays)
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "width*height must equal n_rays");
+    if (width > 0x1000000u || height > 0x1000000u) return fail(c, RT_ERR_INVALID_ARGUMENT, "grid too large");
+    c->pinhole = true;
+    c->width = width;
+    c->height = height;
+    c->z = z;
+    return RT_OK;
+}
+
+int rt_set_shard(rt_context* c, uint64_t tile_rays, uint32_t rank, uint32_t world) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (world == 0 || rank >= world || (world > 1 && tile_rays == 0))
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "need world >= 1, rank < world, tile_rays > 0");
+    c->tile_rays = tile_rays;
+    c->rank = rank;
+    c->world = world;
+    c->n_local = local_count(c->n_rays, tile_rays, rank, world);
+    return RT_OK;
+}
+
+uint64_t rt_local_rays(const rt_context* c) { return c ? c->n_local : 0; }
+
+int rt_set_aux_device(rt_context* c, void* d_hit_t, void* d_hit_index) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    c->aux_t = static_cast<float*>(d_hit_t);
+    c->aux_index = static_cast<int32_t*>(d_hit_index);
+    return RT_OK;
+}
+
+int rt_render_device(rt_context* c, void* d_out, void* hip_stream) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    if (!d_out && c->n_local) return fail(c, RT_ERR_INVALID_ARGUMENT, "d_out is NULL");
+    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
+    return do_launch(c, d_out, s, false);
+}
+
+int rt_render(rt_context* c, const float** out) {
+    if (!c || !out) return RT_ERR_INVALID_ARGUMENT;
+    int rc = ensure_out(c);
+    if (rc) return rc;
+    rc = ensure_host_out(c);
+    if (rc) return rc;
+    rc = do_launch(c, c->d_out, c->stream, false);
+    if (rc) return rc;
+    const size_t bytes = (size_t)c->n_local * elem_bytes(c);
+    if (bytes) RT_HIP(c, hipMemcpyAsync(c->h_out, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));  // Render() is synchronous (OpenCLRaytracer.cpp:94)
+    *out = static_cast<const float*>(c->h_out);
+    return RT_OK;
+}
+
+int rt_render_aux(rt_context* c, float* hit_t, int32_t* hit_index) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    int rc = ensure_out(c);
+    if (rc) return rc;
+    float* d_t = nullptr;
+    int32_t* d_i = nullptr;
+    const size_t n = (size_t)c->n_local;
+    RT_HIP(c, hipSetDevice(c->device));
+    if (hit_t) RT_HIP(c, hipMalloc((void**)&d_t, n ? n * 4 : 4));
+    if (hit_index) {
+        hipError_t e = hipMalloc((void**)&d_i, n ? n * 4 : 4);
+        if (e != hipSuccess) { if (d_t) (void)hipFree(d_t); return fail_hip(c, e, "hipMalloc aux"); }
+    }
+    c->aux_t = d_t;
+    c->aux_index = d_i;
+    rc = do_launch(c, c->d_out, c->stream, false);
+    hipError_t e = hipSuccess;
+    if (rc == RT_OK) e = hipStreamSynchronize(c->stream);
+    if (rc == RT_OK && e == hipSuccess && hit_t && n) e = hipMemcpy(hit_t, d_t, n * 4, hipMemcpyDeviceToHost);
+    if (rc == RT_OK && e == hipSuccess && hit_index && n) e = hipMemcpy(hit_index, d_i, n * 4, hipMemcpyDeviceToHost);
+    if (d_t) (void)hipFree(d_t);
+    if (d_i) (void)hipFree(d_i);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail_hip(c, e, "aux read-back");
+    return RT_OK;
+}
+
+int rt_count_rays(rt_context* c) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    int rc = ensure_out(c);
+    if (rc) return rc;
+    rc = do_launch(c, c->d_out, c->stream, true);
+    if (rc) return rc;
+    if (c->n_local == 0) return RT_OK;
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(&c->counters, c->d_counters, sizeof(rt::Counters), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_get_stats(rt_context* c, rt_stats_t* s) {
+    if (!c || !s) return RT_ERR_INVALID_ARGUMENT;
+    if (c->ev_count) {
+        const uint32_t slot = (c->ev_count - 1) % kTimingSlots;
+        RT_HIP(c, hipEventSynchronize(c->ev_end[slot]));
+        RT_HIP(c, hipEventElapsedTime(&c->last_ms, c->ev_begin[slot], c->ev_end[slot]));
+    }
+    s->rays_traced = c->counters.traced;
+    s->rays_reference = c->counters.reference;
+    s->hit_pixels = c->counters.hits;
+    s->last_kernel_ms = c->last_ms;
+    s->pinhole = c->pinhole ? 1u : 0u;
+    s->width = c->pinhole ? c->width : 0;
+    s->height = c->pinhole ? c->height : 0;
+    s->local_rays = c->n_local;
+    return RT_OK;
+}
+
+int rt_timing_reset(rt_context* c) {
+    if (!c) return RT_ERR_INVALID_ARGUMENT;
+    c->ev_count = 0;
+    return RT_OK;
+}
+
+int rt_timing_summary(rt_context* c, double* sum_ms, uint32_t* launches) {
+    if (!c || !sum_ms || !launches) return RT_ERR_INVALID_ARGUMENT;
+    const uint32_t n = c->ev_count < kTimingSlots ? c->ev_count : kTimingSlots;
+    double total = 0.0;
+    for (uint32_t i = 0; i < n; ++i) {
+        float ms = 0.f;
+        RT_HIP(c, hipEventSynchronize(c->ev_end[i]));
+        RT_HIP(c, hipEventElapsedTime(&ms, c->ev_begin[i], c->ev_end[i]));
+        total += ms;
+    }
+    *sum_ms = total;
+    *launches = n;
+    return RT_OK;
+}
+
+void rt_destroy(rt_context* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_hot) (void)hipFree(c->d_hot);
+    if (c->d_cold) (void)hipFree(c->d_cold);
+    if (c->d_lights) (void)hipFree(c->d_lights);
+    if (c->d_rays) (void)hipFree(c->d_rays);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->ev_created) {
+        for (uint32_t i = 0; i < kTimingSlots; ++i) {
+            (void)hipEventDestroy(c->ev_begin[i]);
+            (void)hipEventDestroy(c->ev_end[i]);
+        }
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+}  // extern "C"

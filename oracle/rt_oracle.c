@@ -1,0 +1,368 @@
+/* TEST INFRASTRUCTURE - not product code.
+ *
+ * CPU restatement of the reference's per-pixel hot path (hittest / shade /
+ * shade_and_reflect), written from the reference's algorithm, NOT a copy of its
+ * source. Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product path (opencl-raytracer_amd/csrc) never does.
+ *
+ * Pinning: this restatement is validated bit-for-bit against the reference's own
+ * kernels compiled verbatim for the host (oracle/_ref, see oracle/Makefile) by
+ * tests/test_oracle_vs_ref.py in the build container, and against the committed golden
+ * vectors generated from those kernels (tests/golden/, tests/golden/make_golden.py).
+ * The reference itself ships no tests or golden vectors.
+ *
+ * Floating point contract (re-derived from the LLVM IR of the reference
+ * kernels under `clang -x cl -cl-std=CL2.0`):
+ *   - this file is compiled with -ffp-contract=off; every place where the OpenCL
+ *     front-end forms llvm.fmuladd is written FMA(a,b,c) below. RT_FUSED=1 maps FMA to a
+ *     single-rounding fmaf (what an FMA-capable OpenCL device executes), RT_FUSED=0 to
+ *     a*b followed by +c (x86 baseline). Everything else is a plain IEEE op.
+ *   - sum-of-products `p0 + p1 + p2 (+ p3)`: clang fuses the FIRST product onto the
+ *     SECOND (plain) product, then each later product onto the running sum:
+ *         t = b*y ; t = FMA(a,x,t) ; t = FMA(c,z,t) ; t = FMA(d,w,t)
+ *   - sqrt and / are IEEE correctly rounded; pow is libm powf;
+ *     dot / normalize are defined by oracle/ref_shim.cl (unfused, left to right).
+ *
+ * Record layouts are the device layouts of the reference (SURVEY.md 2.1;
+ * shade_and_reflect_kernel.cl:1-29, OpenCLRaytracer.hpp:25-58): ObjectData 320 B,
+ * Light 64 B, Ray 32 B, pixel 16 B.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#ifndef RT_FUSED
+#define RT_FUSED 1
+#endif
+
+#if RT_FUSED
+#define FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+#else
+#define FMA(a, b, c) ((a) * (b) + (c)) /* compiled with -ffp-contract=off: two roundings */
+#endif
+
+#define RT_MAX_FLOAT 3.402823466e+38F /* shade_and_reflect_kernel.cl:31 */
+
+/* float-index offsets inside the 320-byte ObjectData record */
+enum { OBJ_STRIDE = 80, OBJ_MAT = 0, OBJ_MV = 16, OBJ_MVINV = 32, OBJ_TYPE = 64 };
+enum { MAT_AMB = 0, MAT_DIF = 4, MAT_SPEC = 8, MAT_ABSORB = 12, MAT_SHINE = 15 };
+enum { LIGHT_STRIDE = 16, LIGHT_AMB = 0, LIGHT_DIF = 4, LIGHT_SPEC = 8, LIGHT_POS = 12 };
+enum { RAY_STRIDE = 8 };
+
+typedef struct {
+    float mat[16];   /* Material, device layout */
+    float inter[4];  /* view-space intersection (float4, w carried) */
+    float normal[3];
+    float refl[3];
+    float time;
+    int index;       /* not in the reference: winning object index, for parity reporting */
+} Hit;
+
+typedef struct {
+    uint64_t rays_ref; /* rays the reference semantics trace (SURVEY.md 8d R_ref) */
+} Counters;
+
+/* ---- builtins, as defined by oracle/ref_shim.cl ---------------------------------- */
+static inline float dot3(const float* a, const float* b) {
+    float s = a[0] * b[0];
+    s = s + a[1] * b[1];
+    s = s + a[2] * b[2];
+    return s;
+}
+static inline void normalize3(float* o, const float* v) {
+    float s = v[0] * v[0];
+    s = s + v[1] * v[1];
+    s = s + v[2] * v[2];
+    float len = sqrtf(s);
+    o[0] = v[0] / len;
+    o[1] = v[1] / len;
+    o[2] = v[2] / len;
+}
+
+/* transform(): column-major M * v (shade_and_reflect_kernel.cl:60-65) */
+static inline void xform4(float* o, const float* m, const float* v) {
+    for (int r = 0; r < 4; ++r) {
+        float t = m[4 + r] * v[1];
+        t = FMA(m[r], v[0], t);
+        t = FMA(m[8 + r], v[2], t);
+        t = FMA(m[12 + r], v[3], t);
+        o[r] = t;
+    }
+}
+
+/* one slab of the unit box (intersectsWidthBoxSide, shade_and_reflect_kernel.cl:33-58) */
+static inline int box_slab(float* tmin, float* tmax, float start, float dir) {
+    float t1 = -0.5f - start;
+    float t2 = 0.5f - start;
+    if (dir == 0) {
+        if (copysignf(t1, t2) == t1) return 0;
+        *tmin = -RT_MAX_FLOAT;
+        *tmax = RT_MAX_FLOAT;
+        return 1;
+    }
+    t1 = t1 / dir;
+    t2 = t2 / dir;
+    if (dir < 0) {
+        *tmin = fminf(t1, t2);
+        *tmax = fmaxf(t1, t2);
+    } else {
+        *tmin = t1;
+        *tmax = t2;
+    }
+    return 1;
+}
+
+/* On an accepted hit: intersection = mv * p, normal = normalize((mv * (n,0)).xyz), copy material
+ * (shade_and_reflect_kernel.cl:110-119 sphere, :161-166 box). */
+static inline void materialise(Hit* hit, const float* obj, const float* p, const float* n_obj, float t, int index) {
+    hit->time = t;
+    hit->index = index;
+    xform4(hit->inter, obj + OBJ_MV, p);
+    float n4[4] = { n_obj[0], n_obj[1], n_obj[2], 0.0f };
+    float nv[4];
+    xform4(nv, obj + OBJ_MV, n4);
+    normalize3(hit->normal, nv);
+    memcpy(hit->mat, obj + OBJ_MAT, 64);
+}
+
+/* raycast(): closest hit over all objects in ascending index order
+ * (shade_and_reflect_kernel.cl:72-177; shade_kernel.cl:66-168; hittest_kernel.cl:63-147).
+ * variant 2 = shade_and_reflect (reflection vector, `time == MAX` miss test),
+ * variant 1 = shade_kernel (`time < MAX` hit test, no reflection vector). */
+static int raycast(uint64_t count, const float* objs, const float* ray, Hit* hit, int variant) {
+    for (uint64_t k = 0; k < count; ++k) {
+        const float* obj = objs + k * OBJ_STRIDE;
+        float s[4], d[4];
+        xform4(s, obj + OBJ_MVINV, ray);
+        xform4(d, obj + OBJ_MVINV, ray + 4);
+        uint32_t type;
+        memcpy(&type, obj + OBJ_TYPE, 4);
+        if (type == 0) { /* unit sphere */
+            float A = d[1] * d[1];
+            A = FMA(d[0], d[0], A);
+            A = FMA(d[2], d[2], A);
+            float B = s[1] * d[1];
+            B = FMA(d[0], s[0], B);
+            B = FMA(d[2], s[2], B);
+            B = B * 2.0f;
+            float C = s[1] * s[1];
+            C = FMA(s[0], s[0], C);
+            C = FMA(s[2], s[2], C);
+            C = C + -1.0f;
+            float radical = FMA(B, B, (A * 4.0f) * (-C));
+            if (radical < 0) continue;
+            float root = sqrtf(radical);
+            float den = A * 2.0f;
+            float t1 = (-B - root) / den;
+            float t2 = (root - B) / den; /* (-B + root) */
+            float tMin = (t1 >= 0 && t2 >= 0) ? fminf(t1, t2) : fmaxf(t1, t2);
+            if (tMin < 0) continue;
+            if (hit->time < tMin) continue; /* ties: the later sphere wins (Q3) */
+            float p[4];
+            for (int i = 0; i < 4; ++i) p[i] = FMA(tMin, d[i], s[i]);
+            materialise(hit, obj, p, p, tMin, (int)k);
+        } else if (type == 1) { /* unit box [-0.5,0.5]^3 */
+            float txMin, txMax, tyMin, tyMax, tzMin, tzMax;
+            if (!box_slab(&txMin, &txMax, s[0], d[0])) continue;
+            if (!box_slab(&tyMin, &tyMax, s[1], d[1])) continue;
+            if (!box_slab(&tzMin, &tzMax, s[2], d[2])) continue;
+            float tMin = fmaxf(fmaxf(txMin, tyMin), tzMin);
+            float tMax = fminf(fminf(txMax, tyMax), tzMax);
+            if (tMax < tMin) continue;
+            float tHit = (tMin >= 0 && tMax >= 0) ? fminf(tMin, tMax) : fmaxf(tMin, tMax);
+            if (tHit < 0) continue;
+            if (hit->time <= tHit) continue; /* ties: the earlier object wins (Q3) */
+            float p[4];
+            for (int i = 0; i < 4; ++i) p[i] = FMA(tHit, d[i], s[i]);
+            float n[3] = { 0.f, 0.f, 0.f };
+            for (int i = 0; i < 3; ++i) {
+                if (p[i] > 0.4998f) n[i] += 1.f;
+                else if (p[i] < -0.4998f) n[i] -= 1.f;
+            }
+            materialise(hit, obj, p, n, tHit, (int)k);
+        }
+    }
+    if (variant == 1) return hit->time < RT_MAX_FLOAT; /* shade_kernel.cl:167 */
+    if (hit->time == RT_MAX_FLOAT) return 0;            /* shade_and_reflect_kernel.cl:173 */
+    float k2 = dot3(ray + 4, hit->normal) * -2.0f;      /* reflect(), :68-70,:175 */
+    for (int i = 0; i < 3; ++i) hit->refl[i] = FMA(k2, hit->normal[i], ray[4 + i]);
+    return 1;
+}
+
+/* The light loop (shade_and_reflect_kernel.cl:184-242; shade_kernel.cl:199-253).
+ * accumulate = 1: shade_kernel semantics (sum over lights, :252);
+ * accumulate = 0: shade_and_reflect semantics (the LAST light's terms survive, :238),
+ * with the stale-specular carry-over of both (specular only re-assigned when lit and
+ * nDotL > 0, or zeroed when shadowed). */
+static void shade_lights(uint64_t n_objs, const float* objs, uint64_t n_lights, const float* lights, const Hit* hit,
+                         int accumulate, int variant, float* out, Counters* ctr) {
+    const float* P = hit->inter;
+    float color[3] = { 0.f, 0.f, 0.f };
+    float ambient[3] = { 0.f, 0.f, 0.f }, diffuse[3] = { 0.f, 0.f, 0.f }, specular[3] = { 0.f, 0.f, 0.f };
+    for (uint64_t li = 0; li < n_lights; ++li) {
+        const float* light = lights + li * LIGHT_STRIDE;
+        const float* pos = light + LIGHT_POS;
+        float lv[3];
+        if (pos[3] != 0) { for (int i = 0; i < 3; ++i) lv[i] = pos[i] - P[i]; }
+        else             { for (int i = 0; i < 3; ++i) lv[i] = -pos[i]; }
+        float nl[3];
+        normalize3(nl, lv);
+        float sray[8];
+        for (int i = 0; i < 3; ++i) sray[i] = FMA(nl[i], 0.01f, P[i]);
+        sray[3] = FMA(0.0f, 0.01f, 1.0f);
+        sray[4] = lv[0]; sray[5] = lv[1]; sray[6] = lv[2]; sray[7] = 0.0f;
+        Hit sh;
+        sh.time = RT_MAX_FLOAT;
+        sh.index = -1;
+        raycast(n_objs, objs, sray, &sh, variant);
+        ctr->rays_ref += 1;
+
+        float nv[3], vv[3], negP[3], negnl[3], rv[3];
+        normalize3(nv, hit->normal);
+        float nDotL = dot3(nv, nl);
+        for (int i = 0; i < 3; ++i) { negP[i] = -P[i]; negnl[i] = -nl[i]; }
+        normalize3(vv, negP);
+        float kk = dot3(negnl, nv) * -2.0f;
+        for (int i = 0; i < 3; ++i) rv[i] = FMA(kk, nv[i], negnl[i]);
+        normalize3(rv, rv);
+        float rDotV = fmaxf(dot3(rv, vv), 0.0f);
+
+        for (int i = 0; i < 3; ++i) ambient[i] = hit->mat[MAT_AMB + i] * light[LIGHT_AMB + i];
+        if (sh.time >= 1.f || sh.time < 0) {
+            float nd = fmaxf(nDotL, 0.f);
+            for (int i = 0; i < 3; ++i) diffuse[i] = (hit->mat[MAT_DIF + i] * light[LIGHT_DIF + i]) * nd;
+            if (nDotL > 0) {
+                float pw = powf(rDotV, fmaxf(hit->mat[MAT_SHINE], 1.f));
+                for (int i = 0; i < 3; ++i) specular[i] = (hit->mat[MAT_SPEC + i] * light[LIGHT_SPEC + i]) * pw;
+            }
+        } else {
+            for (int i = 0; i < 3; ++i) { diffuse[i] = 0.f; specular[i] = 0.f; }
+        }
+        if (accumulate) { for (int i = 0; i < 3; ++i) color[i] = ((color[i] + ambient[i]) + diffuse[i]) + specular[i]; }
+        else            { for (int i = 0; i < 3; ++i) color[i] = (ambient[i] + diffuse[i]) + specular[i]; }
+    }
+    out[0] = color[0]; out[1] = color[1]; out[2] = color[2];
+}
+
+/* __kernel shade_and_reflect (shade_and_reflect_kernel.cl:244-285). Returns 1 when the pixel is written. */
+static int pixel_shade_and_reflect(uint32_t max_bounces, uint64_t n_objs, const float* objs, uint64_t n_lights,
+                                   const float* lights, const float* ray, float* rgb, Hit* primary, Counters* ctr) {
+    Hit hit;
+    hit.time = RT_MAX_FLOAT;
+    hit.index = -1;
+    ctr->rays_ref += 1;
+    int got = raycast(n_objs, objs, ray, &hit, 2);
+    *primary = hit;
+    if (!got) return 0;
+
+    float absorb[3], reflc[3] = { 0.f, 0.f, 0.f }, sh[3];
+    shade_lights(n_objs, objs, n_lights, lights, &hit, 0, 2, sh, ctr);
+    for (int i = 0; i < 3; ++i) absorb[i] = sh[i] * hit.mat[MAT_ABSORB];
+    float ap = hit.mat[MAT_ABSORB];
+
+    uint32_t bounces = max_bounces;
+    float rray[8], nd[3];
+    normalize3(nd, hit.refl);
+    for (int i = 0; i < 3; ++i) rray[i] = FMA(nd[i], 0.001f, hit.inter[i]);
+    rray[3] = FMA(0.0f, 0.001f, hit.inter[3]);
+    rray[4] = hit.refl[0]; rray[5] = hit.refl[1]; rray[6] = hit.refl[2]; rray[7] = 0.0f;
+    Hit rh;
+    rh.time = RT_MAX_FLOAT;
+    rh.index = -1;
+
+    /* while (bounces-- > 0 && raycast(...) && absorptionPercent <= 0.999f)   (:268) */
+    for (;;) {
+        uint32_t before = bounces;
+        bounces = bounces - 1u; /* unsigned post-decrement happens whether or not the test passes */
+        if (!(before > 0)) break;
+        ctr->rays_ref += 1;
+        if (!raycast(n_objs, objs, rray, &rh, 2)) break;
+        if (!(ap <= 0.999f)) break;
+        shade_lights(n_objs, objs, n_lights, lights, &rh, 0, 2, reflc, ctr);
+        float ra = (1.f - ap) * rh.mat[MAT_ABSORB];
+        for (int i = 0; i < 3; ++i) absorb[i] = FMA(ra, reflc[i], absorb[i]);
+        ap = ap + ra;
+        normalize3(nd, rh.refl);
+        for (int i = 0; i < 3; ++i) rray[i] = FMA(nd[i], 0.001f, rh.inter[i]);
+        rray[3] = FMA(0.0f, 0.001f, rh.inter[3]);
+        rray[4] = rh.refl[0]; rray[5] = rh.refl[1]; rray[6] = rh.refl[2]; rray[7] = 0.0f;
+        rh.time = RT_MAX_FLOAT;
+    }
+    if (bounces == 0 && ap < 1.f) {
+        float w = 1.f - ap;
+        for (int i = 0; i < 3; ++i) absorb[i] = FMA(w, reflc[i], absorb[i]);
+    }
+    rgb[0] = absorb[0]; rgb[1] = absorb[1]; rgb[2] = absorb[2];
+    return 1;
+}
+
+/* __kernel shade (shade_kernel.cl:180-258) */
+static int pixel_shade(uint64_t n_objs, const float* objs, uint64_t n_lights, const float* lights, const float* ray,
+                       float* rgb, Hit* primary, Counters* ctr) {
+    Hit hit;
+    hit.time = RT_MAX_FLOAT;
+    hit.index = -1;
+    ctr->rays_ref += 1;
+    int got = raycast(n_objs, objs, ray, &hit, 1);
+    *primary = hit;
+    if (!got) return 0;
+    shade_lights(n_objs, objs, n_lights, lights, &hit, 1, 1, rgb, ctr);
+    return 1;
+}
+
+int rto_fused(void) { return RT_FUSED; }
+
+/* Run `count` work-items starting at `first`.
+ *   kernel: 0 hittest, 1 shade, 2 shade_and_reflect
+ *   out:    kernel 0: float per work-item (index i), written only on a hit (hittest_kernel.cl:149)
+ *           kernel 1/2: 4 floats per work-item, RGB written only on a hit (.w left untouched)
+ *   hit_index / hit_t (optional, may be NULL): primary-ray winner index (-1 on miss) and t
+ *   rays_ref (optional): number of rays the reference semantics traced
+ * Returns the number of threads used. */
+int rto_render(int kernel, uint32_t max_bounces, uint32_t n_objs, const void* objs_, uint32_t n_lights,
+               const void* lights_, const void* rays_, void* out_, uint64_t first, uint64_t count,
+               int32_t* hit_index, float* hit_t, uint64_t* rays_ref, int threads)
+{
+    const float* objs = (const float*)objs_;
+    const float* lights = (const float*)lights_;
+    const float* rays = (const float*)rays_;
+    float* out = (float*)out_;
+    uint64_t total_rays = 0;
+    int used = 1;
+#ifdef _OPENMP
+    if (threads <= 0) threads = omp_get_max_threads();
+    used = threads;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(+ : total_rays)
+#endif
+    for (int64_t i = (int64_t)first; i < (int64_t)(first + count); ++i) {
+        const float* ray = rays + (uint64_t)i * RAY_STRIDE;
+        Counters ctr = { 0 };
+        Hit primary;
+        primary.time = RT_MAX_FLOAT;
+        primary.index = -1;
+        if (kernel == 0) {
+            /* hittest keeps only the nearest t; same candidate/tie rules as raycast() */
+            ctr.rays_ref += 1;
+            raycast(n_objs, objs, ray, &primary, 1);
+            if (primary.time < RT_MAX_FLOAT) out[i] = primary.time;
+        } else if (kernel == 1) {
+            float rgb[3];
+            if (pixel_shade(n_objs, objs, n_lights, lights, ray, rgb, &primary, &ctr)) {
+                out[4 * i + 0] = rgb[0]; out[4 * i + 1] = rgb[1]; out[4 * i + 2] = rgb[2];
+            }
+        } else {
+            float rgb[3];
+            if (pixel_shade_and_reflect(max_bounces, n_objs, objs, n_lights, lights, ray, rgb, &primary, &ctr)) {
+                out[4 * i + 0] = rgb[0]; out[4 * i + 1] = rgb[1]; out[4 * i + 2] = rgb[2];
+            }
+        }
+        if (hit_index) hit_index[i] = primary.index;
+        if (hit_t) hit_t[i] = primary.time;
+        total_rays += ctr.rays_ref;
+    }
+    if (rays_ref) *rays_ref = total_rays;
+    return used;
+}

@@ -1,0 +1,20 @@
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT), str(ROOT / "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def restatement():
+    """fused/unfused CPU restatements (the oracle). Built on demand."""
+    from oracle import oracle
+    return {True: oracle.Restatement(True), False: oracle.Restatement(False)}

@@ -1,0 +1,134 @@
+"""Shared test utilities: seeded scene builders and HIP-vs-oracle comparison."""
+from __future__ import annotations
+
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import _pkg  # noqa: E402
+
+pkg = _pkg.load()
+from opencl_raytracer_amd import camera, records as R  # noqa: E402
+
+F = np.float32
+SCENES = ROOT / "scenes"
+GOLDEN = ROOT / "tests" / "golden"
+
+
+def rotation(axis, angle):
+    axis = np.asarray(axis, dtype=np.float64)
+    axis = axis / np.linalg.norm(axis)
+    x, y, z = axis
+    c, s = np.cos(angle), np.sin(angle)
+    C = 1 - c
+    return np.array([[c + x * x * C, x * y * C - z * s, x * z * C + y * s],
+                     [y * x * C + z * s, c + y * y * C, y * z * C - x * s],
+                     [z * x * C - y * s, z * y * C + x * s, c + z * z * C]])
+
+
+def instance(translate, rot3=None, scale=(1, 1, 1)):
+    """mv = T * R * S and its inverse (float64 math, rounded to float32; inputs are just bytes)."""
+    Rm = np.eye(3) if rot3 is None else rot3
+    S = np.diag(np.asarray(scale, dtype=np.float64))
+    A = Rm @ S
+    mv = np.eye(4)
+    mv[:3, :3] = A
+    mv[:3, 3] = translate
+    inv = np.eye(4)
+    Ai = np.linalg.inv(A)
+    inv[:3, :3] = Ai
+    inv[:3, 3] = -Ai @ np.asarray(translate, dtype=np.float64)
+    # column-major storage: element [c][r]
+    return mv.T.astype(F).copy(), inv.T.astype(F).copy()
+
+
+def random_scene(n_spheres, n_boxes, n_lights, seed, absorption=None, directional_lights=0, spread=6.0,
+                 zrange=(-30.0, -8.0), nonuniform=True):
+    """Random mixed scene in front of the camera; object order is shuffled so types interleave."""
+    rng = np.random.default_rng(seed)
+    objs = []
+    types = [R.SPHERE] * n_spheres + [R.BOX] * n_boxes
+    rng.shuffle(types)
+    for t in types:
+        pos = (rng.uniform(-spread, spread), rng.uniform(-spread, spread), rng.uniform(*zrange))
+        rot = rotation(rng.normal(size=3), rng.uniform(0, 2 * np.pi))
+        sc = rng.uniform(0.4, 1.6, size=3) if nonuniform else np.full(3, rng.uniform(0.4, 1.6))
+        mv, inv = instance(pos, rot, sc)
+        a = absorption if absorption is not None else rng.choice([1.0, 0.9995, 0.999, 0.7, 0.5, 0.2])
+        mat = R.Material(ambient=rng.uniform(0, 1, 3), diffuse=rng.uniform(0, 1, 3), specular=rng.uniform(0, 1, 3),
+                         absorption=a, reflection=1 - a, shininess=rng.choice([0.5, 1.0, 5.0, 30.0, 100.0]))
+        objs.append(R.make_object(t, mat, mv, inv))
+    lights = []
+    for i in range(n_lights):
+        props = R.LightProperties(ambient=rng.uniform(0, .2, 3), diffuse=rng.uniform(0, .6, 3),
+                                  specular=rng.uniform(0, .6, 3))
+        if i < directional_lights:
+            d = rng.normal(size=3)
+            lights.append(R.make_light(props, position=(d[0], d[1], d[2] - 1.0, 0.0)))
+        else:
+            lights.append(R.make_light(props, position=(rng.uniform(-15, 15), rng.uniform(-15, 15),
+                                                         rng.uniform(-5, 12), 1.0)))
+    return R.objects_array(objs), R.lights_array(lights)
+
+
+def rgb_bits(a):
+    return np.ascontiguousarray(a[:, :3]).view(np.uint32)
+
+
+def compare_frames(hip_out, oracle_out, atol=1e-5):
+    """max |dRGB| over all pixels (the north_star's colour bar is 1e-5 absolute)."""
+    d = np.abs(hip_out[:, :3].astype(np.float64) - oracle_out[:, :3].astype(np.float64))
+    return float(d.max()) if d.size else 0.0
+
+
+def fixture_names():
+    return sorted(p.stem for p in GOLDEN.glob("*.npz"))
+
+
+def load_fixture(name):
+    """Golden vector written by tests/golden/make_golden.py from the reference's own kernels."""
+    z = np.load(GOLDEN / f"{name}.npz")
+    objs = np.frombuffer(z["objs"].tobytes(), dtype=R.OBJECT_DTYPE).copy()
+    lights = np.frombuffer(z["lights"].tobytes(), dtype=R.LIGHT_DTYPE).copy()
+    if "rays" in z.files:
+        rays = np.frombuffer(z["rays"].tobytes(), dtype=R.RAY_DTYPE).copy()
+        cam = None
+    else:
+        w, h, fov = z["camera"]
+        cam = (int(w), int(h), float(fov))
+        rays = camera.primary_rays(cam[0], cam[1], cam[2])
+    return dict(name=name, objs=objs, lights=lights, rays=rays, camera=cam, kernel=int(z["kernel"]),
+                max_bounces=int(z["max_bounces"]), out_fused=z["out_fused"], out_unfused=z["out_unfused"])
+
+
+def expected_full(fx, fused):
+    """Golden output expanded to the buffer the backends return (misses = background / MAX_FLOAT)."""
+    out = fx["out_fused"] if fused else fx["out_unfused"]
+    if fx["kernel"] == 0:
+        return out
+    full = np.zeros((out.shape[0], 4), dtype=np.float32)
+    full[:, :3] = out
+    full[:, 3] = 1.0
+    return full
+
+
+def same_floats(a, b):
+    """Exact float equality, element for element. The only tolerated bit difference is the sign of a zero:
+    OpenCL's fmin/fmax may return either of (-0, +0), so the reference's own output is implementation-defined
+    there (x86 maxss vs gfx950 v_max_f32 differ); NaNs must match NaNs."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    if a.shape != b.shape:
+        return False
+    return bool(np.all((a == b) | (np.isnan(a) & np.isnan(b))))
+
+
+def count_float_mismatches(a, b):
+    a = np.asarray(a)
+    b = np.asarray(b)
+    return int(np.sum(~((a == b) | (np.isnan(a) & np.isnan(b)))))

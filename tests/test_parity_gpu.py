@@ -1,0 +1,180 @@
+"""GPU: the HIP path (through the C ABI) against the golden vectors of the reference's own kernels and
+against the CPU oracle on seeded scenes.
+
+Bars (BASELINE.json north_star): primary hit object index and nearest t exact (helpers.same_floats: exact
+float equality, signed zero excepted); shaded RGB within 1e-5 absolute (in practice <= 2 ulp: the only
+non-shared arithmetic is powf - OCML on the GPU, libm on the CPU); the reference-equivalent ray count must
+equal the oracle's, which pins the hit/miss structure of every secondary ray.
+"""
+import numpy as np
+import pytest
+
+from helpers import (R, camera, compare_frames, count_float_mismatches, expected_full, fixture_names, load_fixture,
+                     random_scene, same_floats)
+
+pytestmark = pytest.mark.gpu
+
+RGB_ATOL = 1e-5  # north_star tolerance for floating-point colour
+NAMES = fixture_names()
+KNAME = {0: "hittest", 1: "shade", 2: "shade_and_reflect"}
+
+
+def hip(*a, **k):
+    from opencl_raytracer_amd.hip_raytracer import HIPRaytracer
+    return HIPRaytracer(*a, **k)
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_vectors(name, fused):
+    fx = load_fixture(name)
+    want = expected_full(fx, fused)
+    for literal in (False, True):
+        with hip(fx["objs"], fx["lights"], fx["rays"], fx["max_bounces"], kernel=fx["kernel"], fused=fused,
+                 literal=literal) as rt:
+            got = rt.Render()
+        if fx["kernel"] == 0:
+            assert same_floats(got, want), f"{name}: {count_float_mismatches(got, want)} nearest-t values differ"
+        else:
+            assert got.shape == want.shape
+            assert compare_frames(got, want) <= RGB_ATOL
+            # hit/miss mask must be identical: background pixels are exactly (0,0,0)
+            assert np.array_equal(np.any(got[:, :3] != 0, axis=1), np.any(want[:, :3] != 0, axis=1))
+            assert np.all(got[:, 3] == 1.0)
+
+
+def test_index_recovery_matches_reference_index():
+    """The reference's `shade` output in this fixture IS its hit index; compare with the HIP aux index."""
+    fx = load_fixture("index_recovery_shade")
+    ref_rgb = fx["out_fused"]
+    ref_index = np.rint(ref_rgb[:, 0] * 256 + ref_rgb[:, 1] * 65536).astype(np.int64) - 1
+    with hip(fx["objs"], fx["lights"], fx["rays"], 0, kernel="shade") as rt:
+        _, idx = rt.render_aux()
+    assert np.array_equal(idx.astype(np.int64), ref_index)
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
+@pytest.mark.parametrize("seed,n_s,n_b,n_l,res", [(201, 30, 20, 3, (64, 48)), (202, 0, 40, 2, (48, 48)),
+                                                   (203, 200, 100, 6, (48, 32)), (204, 5, 5, 1, (128, 96))])
+def test_random_scenes_vs_oracle(seed, n_s, n_b, n_l, res, fused, restatement):
+    objs, lights = random_scene(n_s, n_b, n_l, seed=seed, directional_lights=seed % 2, spread=7.0)
+    rays = camera.primary_rays(*res)
+    for kernel in ("hittest", "shade", "shade_and_reflect"):
+        want = restatement[fused].render(kernel, objs, lights, rays, 3)
+        outs = {}
+        for literal in (False, True):
+            for raygen in (True, False):
+                with hip(objs, lights, rays, 3, kernel=kernel, fused=fused, literal=literal, raygen=raygen) as rt:
+                    out = rt.Render()
+                    t, idx = rt.render_aux()
+                    st = rt.count_rays()
+                assert st.pinhole == int(raygen)
+                assert np.array_equal(idx, want["hit_index"]), f"{kernel}: primary hit index differs"
+                assert same_floats(t, want["hit_t"]), f"{kernel}: primary t differs"
+                assert st.rays_reference == want["rays_ref"], f"{kernel}: reference-equivalent ray count differs"
+                if literal:
+                    assert st.rays_traced == st.rays_reference
+                else:
+                    assert st.rays_traced <= st.rays_reference
+                if kernel == "hittest":
+                    assert same_floats(out, want["out"])
+                else:
+                    assert compare_frames(out, want["out"]) <= RGB_ATOL
+                outs[(literal, raygen)] = out
+        # the exact eliminations and in-kernel ray generation must not change a single bit
+        base = outs[(True, False)]
+        for key, o in outs.items():
+            assert np.array_equal(o.view(np.uint32), base.view(np.uint32)), f"{kernel} {key} differs from literal"
+
+
+def test_config2_multiple_spheres_1080p_properties(restatement):
+    """BASELINE config 2 at full size: 1920x1080 `shade`. Checked against the oracle on sampled rows and
+    through size-independent properties (idempotence; shard union == full frame)."""
+    from helpers import SCENES
+    from opencl_raytracer_amd import scene_loader
+    objs, lights = scene_loader.load_scene(str(SCENES / "multipleSpheres.txt"))
+    W, H = 1920, 1080
+    z = float(camera.camera_z(H))
+    with hip(objs, lights, None, 0, kernel="shade", camera=(W, H, z)) as rt:
+        a = rt.Render()
+        b = rt.Render()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        full = a.reshape(H, W, 4)
+    rows = [0, 1, 269, 270, 539, 540, 541, 700, 1079]
+    for r in rows:
+        rays = camera.primary_rays(W, H, row_begin=r, row_end=r + 1)
+        want = restatement[True].render("shade", objs, lights, rays, 0)["out"]
+        assert compare_frames(full[r], want) <= RGB_ATOL
+        assert np.array_equal(np.any(full[r][:, :3] != 0, axis=1), np.any(want[:, :3] != 0, axis=1))
+    # shards: 2-row tiles over 3 ranks, reassembled, must equal the full frame bit for bit
+    tile = 2 * W
+    pieces = []
+    for rank in range(3):
+        with hip(objs, lights, None, 0, kernel="shade", camera=(W, H, z)) as rt:
+            rt.set_shard(tile, rank, 3)
+            pieces.append(rt.Render())
+    from opencl_raytracer_amd.sharding import assemble_frame
+    frame = assemble_frame(pieces, tile, W * H)
+    assert np.array_equal(frame.view(np.uint32), a.view(np.uint32))
+
+
+def test_config3_simple_scene_4096_properties(restatement):
+    """BASELINE config 3 at full size (4096x4096, shade_and_reflect, D=3): sampled rows against the oracle,
+    checksum stability, and buffer-rays == generated-rays on a band."""
+    from helpers import SCENES
+    from opencl_raytracer_amd import scene_loader
+    objs, lights = scene_loader.load_scene(str(SCENES / "simpleScene.txt"))
+    W = H = 4096
+    z = float(camera.camera_z(H))
+    with hip(objs, lights, None, 3, kernel="shade_and_reflect", camera=(W, H, z)) as rt:
+        full = rt.Render().reshape(H, W, 4)
+        st = rt.count_rays()
+    assert st.rays_reference >= W * H
+    hit_rows = [1500, 2047, 2048, 2049, 2600]
+    for r in [0, 4095] + hit_rows:
+        rays = camera.primary_rays(W, H, row_begin=r, row_end=r + 1)
+        want = restatement[True].render("shade_and_reflect", objs, lights, rays, 3)["out"]
+        assert compare_frames(full[r], want) <= RGB_ATOL
+        assert np.array_equal(np.any(full[r][:, :3] != 0, axis=1), np.any(want[:, :3] != 0, axis=1))
+    assert np.any(full[2048][:, :3] != 0)
+    # uploaded ray buffer (no in-kernel generation) on a 64-row band
+    band = camera.primary_rays(W, H, row_begin=2016, row_end=2080)
+    with hip(objs, lights, band, 3, kernel="shade_and_reflect", raygen=False) as rt:
+        got = rt.Render().reshape(64, W, 4)
+    assert np.array_equal(got.view(np.uint32), full[2016:2080].view(np.uint32))
+
+
+def test_empty_and_ragged_inputs():
+    objs, lights = random_scene(3, 3, 2, seed=5)
+    # zero rays
+    with hip(objs, lights, camera.primary_rays(8, 8)[:0], 2) as rt:
+        assert rt.Render().shape == (0, 4)
+    # no objects, no lights
+    rays = camera.primary_rays(33, 7)  # 231 rays: not a multiple of the 256-thread workgroup
+    with hip(R.objects_array([]), R.lights_array([]), rays, 2) as rt:
+        out = rt.Render()
+        assert out.shape == (231, 4) and np.all(out[:, :3] == 0) and np.all(out[:, 3] == 1)
+    with hip(objs, R.lights_array([]), rays, 2) as rt:
+        out = rt.Render()
+        assert np.all(out[:, :3] == 0)
+    # ragged shard: 231 rays in tiles of 50 over 2 ranks
+    from opencl_raytracer_amd.sharding import assemble_frame
+    with hip(objs, lights, rays, 2) as rt:
+        full = rt.Render()
+    pieces = []
+    for rank in range(2):
+        with hip(objs, lights, rays, 2) as rt:
+            rt.set_shard(50, rank, 2)
+            pieces.append(rt.Render())
+    assert np.array_equal(assemble_frame(pieces, 50, 231).view(np.uint32), full.view(np.uint32))
+
+
+def test_errors_are_reported_not_thrown():
+    from opencl_raytracer_amd.hip_raytracer import RTError
+    objs, lights = random_scene(1, 1, 1, seed=1)
+    with pytest.raises(RTError):
+        hip(objs, lights, camera.primary_rays(4, 4), 1, kernel=7)
+    with pytest.raises(RTError):
+        hip(objs, lights, None, 1, camera=(4, 4, -3.0)).set_shard(0, 0, 2)
+    with pytest.raises(RTError):
+        hip(objs, lights, camera.primary_rays(4, 4), 1, device=99)
