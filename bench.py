@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py - throughput of the IRaytracer hot path on MI355X, in BASELINE.json's metric.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3|cfg2|cfg4|cfg4crop|cfg5base]
+
+A step = one frame: every primary ray of the workload through hit-test -> shade -> reflection loop, scene and
+rays resident in HBM before the timed region (rays are regenerated in-kernel from (W,H,z); the framebuffer is
+written to HBM; for N > 1 the step includes the RCCL gather of row-tiles to rank 0).
+Default workload = BASELINE.json configs[2], the single-GPU configuration the metric is quoted on:
+simpleScene, 4096x4096, shade_and_reflect, depth 3.
+
+Prints ONE JSON line (rank 0). `value` is Mrays/s counting the rays the reference semantics trace for the
+frame (primary + shadow + reflection = R_ref, the unit both this backend and the reference are charged for the
+same frame); `rays_traced` is what this backend actually issued after its exact eliminations.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import numpy as np  # noqa: E402
+
+import _pkg  # noqa: E402
+
+_pkg.load()
+from opencl_raytracer_amd import camera, scene_loader, sharding, synthetic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+WORKLOADS = {
+    # name: (description, scene, W, H, kernel, depth)
+    "cfg2": ("multipleSpheres.txt 1920x1080 shade (BASELINE configs[1])", "multipleSpheres", 1920, 1080, "shade", 0),
+    "cfg3": ("simpleScene.txt 4096x4096 shade_and_reflect depth=3 (BASELINE configs[2])", "simpleScene", 4096, 4096, "shade_and_reflect", 3),
+    "cfg5base": ("roundedCube.txt 8192x8192 shade_and_reflect depth=5 (analytic base of BASELINE configs[4])", "roundedCube", 8192, 8192, "shade_and_reflect", 5),
+    "cfg4": ("synthetic 100k spheres + 32 lights 4096x4096 shade_and_reflect depth=3 (BASELINE configs[3])", None, 4096, 4096, "shade_and_reflect", 3),
+    "cfg4crop": ("synthetic 100k spheres + 32 lights, centred 512x512 window of the 4096x4096 grid, depth=3", None, 4096, 4096, "shade_and_reflect", 3),
+}
+
+
+def load_workload(name):
+    desc, scene, W, H, kernel, depth = WORKLOADS[name]
+    if scene is not None:
+        objs, lights = scene_loader.load_scene(str(ROOT / "scenes" / f"{scene}.txt"))
+    else:
+        objs, lights = synthetic.spheres_and_lights(100_000, 32)
+    return desc, objs, lights, W, H, kernel, depth
+
+
+def cpu_baseline(objs, lights, rays, kernel, depth, sample_desc):
+    """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, all host cores."""
+    from oracle import oracle
+    rs = oracle.Restatement(True)
+    threads = os.cpu_count() or 1
+    best = None
+    t_total = 0.0
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res = rs.render(kernel, objs, lights, rays, depth, threads=threads, want_aux=False)
+        dt = time.perf_counter() - t0
+        t_total += dt
+        best = dt if best is None else min(best, dt)
+        if t_total > 20.0:
+            break
+    return {"value": res["rays_ref"] / best / 1e6, "unit": "Mrays/s", "cores": int(res["threads"]), "kind": "port",
+            "sample": sample_desc, "seconds": best}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--tile-rows", type=int, default=16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--literal", action="store_true", help="trace every ray the reference traces (no exact eliminations)")
+    ap.add_argument("--ray-buffer", action="store_true", help="read primary rays from an uploaded buffer instead of in-kernel generation")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    heavy = args.workload in ("cfg4",)
+    steps = args.steps if args.steps is not None else (1 if heavy else 20)
+    warmup = args.warmup if args.warmup is not None else (0 if heavy else 3)
+
+    desc, objs, lights, W, H, kernel, depth = load_workload(args.workload)
+    z = float(camera.camera_z(H))
+    crop = None
+    if args.workload == "cfg4crop":
+        crop = (W // 2 - 256, H // 2 - 256, 512, 512)
+
+    from opencl_raytracer_amd.distributed import ShardedHIPRaytracer
+    from opencl_raytracer_amd.hip_raytracer import HIPRaytracer  # noqa: F401
+
+    if crop is not None:
+        rays = camera.crop_rays(W, H, *crop)
+        rt = ShardedHIPRaytracer(objs, lights, rays, depth, kernel=kernel, tile_rows=args.tile_rows, width=crop[2],
+                                 device_index=local_rank, literal=args.literal)
+        frame_w, frame_h = crop[2], crop[3]
+        ray_source = "buffer"
+    elif args.ray_buffer:
+        rays = camera.primary_rays(W, H)
+        rt = ShardedHIPRaytracer(objs, lights, rays, depth, kernel=kernel, tile_rows=args.tile_rows, width=W,
+                                 device_index=local_rank, literal=args.literal, raygen=False)
+        frame_w, frame_h = W, H
+        ray_source = "buffer"
+    else:
+        rt = ShardedHIPRaytracer(objs, lights, None, depth, camera=(W, H, z), kernel=kernel, tile_rows=args.tile_rows,
+                                 device_index=local_rank, literal=args.literal)
+        frame_w, frame_h = W, H
+        ray_source = "in-kernel pinhole"
+    n_rays = rt.n_rays
+
+    # untimed instrumentation pass: ray counts of this rank's tiles
+    st = rt.rt.count_rays()
+    counts = torch.tensor([st.rays_reference, st.rays_traced, st.hit_pixels], dtype=torch.int64, device=device)
+    if world > 1:
+        dist.all_reduce(counts)
+    rays_ref, rays_act, hit_pixels = (int(x) for x in counts.tolist())
+
+    def step():
+        return rt.Render()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    rt.rt.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        frame = step()
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    kernel_ms_sum, launches = rt.rt.timing_summary()
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        assert frame is not None and frame.shape[0] == n_rays
+        ms_per_step = elapsed / steps * 1e3
+        value = rays_ref * steps / elapsed / 1e6
+        kernel_ms = kernel_ms_sum / max(launches, 1)
+        # algorithmic (compulsory) HBM bytes per launch of this rank's kernel:
+        #   16 B/ray framebuffer write (+ 32 B/ray ray-buffer read when rays come from HBM) + scene as uploaded
+        local = rt.rt.local_rays
+        alg_bytes = 16 * local + (32 * local if ray_source == "buffer" else 0) + 320 * len(objs) + 64 * len(lights)
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        tf = ROOT / "profiles" / f"traffic_{args.workload}.json"
+        if tf.exists() and world == 1:
+            try:
+                traffic = json.loads(tf.read_text())["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s (primary+reflect+shadow) at 4096x4096, 1/2/4/8 GPU; max RGB diff vs ref",
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "width": frame_w, "height": frame_h, "objects": int(len(objs)),
+                       "lights": int(len(lights)), "kernel": kernel, "depth": depth, "primary_rays": ray_source,
+                       "partition": f"row-tiles of {args.tile_rows} rows, interleaved over {world} rank(s), gather to rank 0"
+                       if world > 1 else "single GPU", "arithmetic": "fused (fma where the OpenCL front-end marks fmuladd)",
+                       "literal": bool(args.literal)},
+            "rays_reference": rays_ref, "rays_traced": rays_act, "hit_pixels": hit_pixels,
+            "mrays_traced_per_s": rays_act * steps / elapsed / 1e6,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rt::render_pixels",
+                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            if crop is not None or args.workload == "cfg4":
+                cx, cy, cw, ch = (W // 2 - 16, H // 2 - 16, 32, 32)
+                sample = camera.crop_rays(W, H, cx, cy, cw, ch)
+                sdesc = f"centred {cw}x{ch} window of the {W}x{H} ray grid, same scene"
+            else:
+                rows = min(H, 1024)
+                sample = camera.primary_rays(W, H, row_begin=H // 2 - rows // 2, row_end=H // 2 + rows // 2)
+                sdesc = f"centre {rows} rows of the {W}x{H} ray grid, same scene"
+            out["cpu_baseline"] = cpu_baseline(objs, lights, sample, kernel, depth, sdesc)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    rt.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
