@@ -65,6 +65,9 @@ typedef enum rt_kernel {
 #define RT_FLAG_LITERAL   0x2u /* trace every ray the reference traces (no exact eliminations: any-hit shadow
                                   early-out, backward light scan, dead reflection ray). Results are identical */
 #define RT_FLAG_NO_RAYGEN 0x4u /* never replace an uploaded pinhole ray grid by in-kernel generation            */
+#define RT_FLAG_WAVEFRONT  0x8u  /* force the large-scene path (separate traversal / shading kernels)          */
+#define RT_FLAG_MONOLITHIC 0x10u /* force the small-scene path (one fused kernel per frame); default: chosen by
+                                    object count. Both paths produce identical bits.                          */
 
 typedef struct rt_stats_t {
     uint64_t rays_traced;     /* rays this backend actually issued in the last counted render (R_act)          */
@@ -74,6 +77,8 @@ typedef struct rt_stats_t {
     uint32_t pinhole;         /* 1 if primary rays are generated in-kernel                                     */
     uint32_t width, height;   /* pinhole grid (0 when rays come from the uploaded buffer)                      */
     uint64_t local_rays;      /* work-items this context renders (after rt_set_shard)                          */
+    uint32_t wavefront;       /* 1 if the last render used the large-scene (wavefront) path                    */
+    uint32_t rounds;          /* trace/resume rounds of the last wavefront render                              */
 } rt_stats_t;
 
 /* Build a raytracer for one GPU.
@@ -105,7 +110,8 @@ uint64_t rt_local_rays(const rt_context* ctx);
 int rt_render(rt_context* ctx, const float** out);
 
 /* Asynchronous render into caller-provided DEVICE memory (same element layout) on a caller-provided HIP stream
- * (hipStream_t passed as void*; NULL = the context's own stream). No host synchronisation. */
+ * (hipStream_t passed as void*; NULL = the context's own stream). The small-scene path does not synchronise the
+ * host; the large-scene path synchronises the stream once per trace round (a handful per frame). */
 int rt_render_device(rt_context* ctx, void* d_out, void* hip_stream);
 
 /* Optional per-work-item primary-hit record of the NEXT render: t (float) and winning object index

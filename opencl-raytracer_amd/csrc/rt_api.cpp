@@ -30,6 +30,8 @@ struct rt_context {
     uint32_t n_objs = 0, n_lights = 0, max_bounces = 0;
     uint64_t n_rays = 0;
 
+    rt::HotPair* d_pairs = nullptr;
+    uint32_t n_pairs = 0;
     rt::HotObject* d_hot = nullptr;
     rt::ColdObject* d_cold = nullptr;
     rt::LightRec* d_lights = nullptr;
@@ -52,6 +54,10 @@ struct rt_context {
 
     float* aux_t = nullptr;  // caller-owned device buffers for the next render
     int32_t* aux_index = nullptr;
+
+    rt::WavefrontBuffers wf;
+    bool last_wavefront = false;
+    uint32_t last_rounds = 0;
 
     rt::Counters* d_counters = nullptr;
     rt::Counters counters = {0, 0, 0};
@@ -94,10 +100,21 @@ uint64_t local_count(uint64_t n_rays, uint64_t tile_rays, uint32_t rank, uint32_
 }
 
 // ObjectData[] (320 B AoS, as uploaded by the reference) -> hot traversal stream + cold shading records
-void repack_objects(const rt_object_data* objs, uint32_t n, std::vector<rt::HotObject>& hot,
-                    std::vector<rt::ColdObject>& cold) {
+void repack_objects(const rt_object_data* objs, uint32_t n, std::vector<rt::HotPair>& pairs,
+                    std::vector<rt::HotObject>& hot, std::vector<rt::ColdObject>& cold) {
     hot.resize(n);
     cold.resize(n);
+    // traversal stream: objects 2p and 2p+1 interleaved entry by entry (rows x,y,z of mvInverse)
+    pairs.assign((n + 1) / 2, rt::HotPair{});
+    for (uint32_t i = 0; i < n; ++i) {
+        rt::HotPair& hp = pairs[i / 2];
+        const float* m = objs[i].mvInverse;
+        const int half = (int)(i & 1u);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) hp.m[4 * r + c][half] = m[4 * c + r];
+        (half ? hp.type_b : hp.type_a) = objs[i].type;
+    }
+    if (n & 1u) pairs[n / 2].type_b = 0xffffffffu;  // odd count: the missing partner can never be hit
     for (uint32_t i = 0; i < n; ++i) {
         const rt_object_data& o = objs[i];
         const float* m = o.mvInverse;
@@ -170,6 +187,44 @@ int ensure_host_out(rt_context* c) {
     return RT_OK;
 }
 
+// Scenes with at least this many objects take the wavefront path unless a flag says otherwise: below it the
+// per-round state traffic and launches cost more than the leaner traversal loop saves.
+constexpr uint32_t kWavefrontMinObjects = 512;
+
+bool use_wavefront(const rt_context* c) {
+    if (c->flags & RT_FLAG_WAVEFRONT) return true;
+    if (c->flags & RT_FLAG_MONOLITHIC) return false;
+    return c->n_objs >= kWavefrontMinObjects;
+}
+
+void free_wavefront(rt_context* c) {
+    rt::WavefrontBuffers& b = c->wf;
+    if (b.state) (void)hipFree(b.state);
+    for (int i = 0; i < 2; ++i) {
+        if (b.q_closest[i]) (void)hipFree(b.q_closest[i]);
+        if (b.q_any[i]) (void)hipFree(b.q_any[i]);
+    }
+    if (b.counts) (void)hipFree(b.counts);
+    if (b.h_counts) (void)hipHostFree(b.h_counts);
+    b = rt::WavefrontBuffers{};
+}
+
+int ensure_wavefront(rt_context* c) {
+    rt::WavefrontBuffers& b = c->wf;
+    if (b.capacity >= c->n_local && b.state) return RT_OK;
+    free_wavefront(c);
+    const uint64_t n = c->n_local ? c->n_local : 1;
+    RT_HIP(c, hipMalloc((void**)&b.state, rt::wavefront_state_bytes(n)));
+    for (int i = 0; i < 2; ++i) {
+        RT_HIP(c, hipMalloc((void**)&b.q_closest[i], rt::wavefront_queue_bytes(n)));
+        RT_HIP(c, hipMalloc((void**)&b.q_any[i], rt::wavefront_queue_bytes(n)));
+    }
+    RT_HIP(c, hipMalloc((void**)&b.counts, 2 * sizeof(uint32_t)));
+    RT_HIP(c, hipHostMalloc((void**)&b.h_counts, 2 * sizeof(uint32_t), hipHostMallocDefault));
+    b.capacity = n;
+    return RT_OK;
+}
+
 int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     if (c->n_local == 0) {  // empty launch: nothing to render, nothing to time
         if (count) c->counters = rt::Counters{0, 0, 0};
@@ -181,6 +236,8 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
         return fail(c, RT_ERR_STATE, "no primary rays: rt_create got rays == NULL and rt_set_camera was not called");
     rt::RenderParams p;
     std::memset(&p, 0, sizeof(p));
+    p.scene.pairs = c->d_pairs;
+    p.scene.n_pairs = c->n_pairs;
     p.scene.hot = c->d_hot;
     p.scene.cold = c->d_cold;
     p.scene.lights = c->d_lights;
@@ -210,7 +267,16 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     if (count) RT_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters), stream));
     const uint32_t slot = c->ev_count % kTimingSlots;
     RT_HIP(c, hipEventRecord(c->ev_begin[slot], stream));
-    const hipError_t e = rt::launch_render(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, stream);
+    hipError_t e;
+    c->last_wavefront = use_wavefront(c);
+    c->last_rounds = 0;
+    if (c->last_wavefront) {
+        const int rc = ensure_wavefront(c);
+        if (rc) return rc;
+        e = rt::launch_wavefront(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, c->wf, stream, &c->last_rounds);
+    } else {
+        e = rt::launch_render(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, stream);
+    }
     if (e != hipSuccess) return fail_hip(c, e, "kernel launch");
     RT_HIP(c, hipEventRecord(c->ev_end[slot], stream));
     c->ev_count += 1;
@@ -236,8 +302,10 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
     if (kernel < 0 || kernel > 2) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "kernel must be 0, 1 or 2");
     if ((n_objs && !objs) || (n_lights && !lights))
         return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "objs/lights is NULL with a non-zero count");
-    if (flags & ~(RT_FLAG_UNFUSED | RT_FLAG_LITERAL | RT_FLAG_NO_RAYGEN))
+    if (flags & ~(RT_FLAG_UNFUSED | RT_FLAG_LITERAL | RT_FLAG_NO_RAYGEN | RT_FLAG_WAVEFRONT | RT_FLAG_MONOLITHIC))
         return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "unknown flag bits");
+    if ((flags & RT_FLAG_WAVEFRONT) && (flags & RT_FLAG_MONOLITHIC))
+        return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "RT_FLAG_WAVEFRONT and RT_FLAG_MONOLITHIC are exclusive");
 
     int n_dev = 0;
     hipError_t e = hipGetDeviceCount(&n_dev);
@@ -278,9 +346,14 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
     RT_TRY(hipMalloc((void**)&c->d_counters, sizeof(rt::Counters)));
 
     {
+        std::vector<rt::HotPair> pairs;
         std::vector<rt::HotObject> hot;
         std::vector<rt::ColdObject> cold;
-        repack_objects(static_cast<const rt_object_data*>(objs), n_objs, hot, cold);
+        repack_objects(static_cast<const rt_object_data*>(objs), n_objs, pairs, hot, cold);
+        c->n_pairs = (uint32_t)pairs.size();
+        RT_TRY(hipMalloc((void**)&c->d_pairs, sizeof(rt::HotPair) * (pairs.size() + 1)));
+        if (!pairs.empty())
+            RT_TRY(hipMemcpy(c->d_pairs, pairs.data(), sizeof(rt::HotPair) * pairs.size(), hipMemcpyHostToDevice));
         // one spare record keeps the arrays non-null for n_objs == 0
         RT_TRY(hipMalloc((void**)&c->d_hot, sizeof(rt::HotObject) * (size_t)(n_objs + 1)));
         RT_TRY(hipMalloc((void**)&c->d_cold, sizeof(rt::ColdObject) * (size_t)(n_objs + 1)));
@@ -423,6 +496,8 @@ int rt_get_stats(rt_context* c, rt_stats_t* s) {
     s->width = c->pinhole ? c->width : 0;
     s->height = c->pinhole ? c->height : 0;
     s->local_rays = c->n_local;
+    s->wavefront = c->last_wavefront ? 1u : 0u;
+    s->rounds = c->last_rounds;
     return RT_OK;
 }
 
@@ -451,6 +526,7 @@ void rt_destroy(rt_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_hot) (void)hipFree(c->d_hot);
     if (c->d_cold) (void)hipFree(c->d_cold);
     if (c->d_lights) (void)hipFree(c->d_lights);
@@ -458,6 +534,7 @@ void rt_destroy(rt_context* c) {
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    free_wavefront(c);
     if (c->ev_created) {
         for (uint32_t i = 0; i < kTimingSlots; ++i) {
             (void)hipEventDestroy(c->ev_begin[i]);

@@ -175,65 +175,199 @@ __device__ __forceinline__ bool box_candidate(float sx, float sy, float sz, floa
     return true;
 }
 
-// ray -> object space (x,y,z rows only; the w row is needed only by materialise())
+// ---- traversal -------------------------------------------------------------------------------------------
+// Objects are streamed as PAIRS (HotPair, 128 B: every mvInverse entry of objects 2p and 2p+1 side by side).
+// The pair index is wave-uniform, so a pair arrives through two scalar loads and each entry pair sits in an
+// aligned SGPR pair. One v_pk_fma_f32 / v_pk_mul_f32 then does the same multiply-add for BOTH objects:
+// measured on gfx950 a VALU instruction with an SGPR source issues at ~4.4 cycles per wave against ~2.3 for an
+// all-VGPR one, while the packed form with the same SGPR source also costs ~4.3 cycles but retires two
+// objects (scratch/ubench/valu2.hip). Each packed lane is an ordinary IEEE fp32 mul / fma, so every bit of
+// s_obj, d_obj and the discriminant is identical to the one-object-at-a-time evaluation.
+//
+// The packed part is only a FILTER: it computes the reference's `radical` for both spheres of a pair; lanes
+// where `radical < 0` is false for either object (a candidate, or a NaN) take the rare path, which runs the
+// reference's full sphere test (sqrt, two IEEE divides, root choice, tie rule) on the same object-space ray.
+// Pairs that contain a box (or an unknown type) take the generic per-object path.
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct HotPair {       // 128 B, 128-B aligned
+    f2 m[12];          // m[4*r + c] = (A.mvInverse[r][c], B.mvInverse[r][c]) for rows r = 0..2
+    uint32_t type_a, type_b;  // 0xffffffff pads an odd object count (never hit)
+    uint32_t pad[6];
+};
+static_assert(sizeof(HotPair) == 128, "layout");
+
+struct RaySplat {      // the ray with every component duplicated into a VGPR pair (built once per ray)
+    f2 sx, sy, sz, sw, dx, dy, dz, dw;
+};
+
+__device__ __forceinline__ RaySplat splat(const Ray& r) {
+    RaySplat q;
+    q.sx = f2{r.sx, r.sx}; q.sy = f2{r.sy, r.sy}; q.sz = f2{r.sz, r.sz}; q.sw = f2{r.sw, r.sw};
+    q.dx = f2{r.dx, r.dx}; q.dy = f2{r.dy, r.dy}; q.dz = f2{r.dz, r.dz}; q.dw = f2{r.dw, r.dw};
+    return q;
+}
+
+template <bool FUSED>
+__device__ __forceinline__ f2 fma2_(f2 a, f2 b, f2 c) {
+    if constexpr (FUSED) return __builtin_elementwise_fma(a, b, c);
+    else return a * b + c;
+}
+
+// both objects of a pair: ray -> object space (rows x,y,z), the reference's association (row4 / row3)
 template <bool FUSED, bool DW0>
-__device__ __forceinline__ void to_object_space(const float4 r0, const float4 r1, const float4 r2, const Ray& ray,
-                                                float& sx, float& sy, float& sz, float& dx, float& dy, float& dz) {
-    sx = row4<FUSED>(r0.x, r0.y, r0.z, r0.w, ray.sx, ray.sy, ray.sz, ray.sw);
-    sy = row4<FUSED>(r1.x, r1.y, r1.z, r1.w, ray.sx, ray.sy, ray.sz, ray.sw);
-    sz = row4<FUSED>(r2.x, r2.y, r2.z, r2.w, ray.sx, ray.sy, ray.sz, ray.sw);
-    if constexpr (DW0) {
-        dx = row3<FUSED>(r0.x, r0.y, r0.z, ray.dx, ray.dy, ray.dz);
-        dy = row3<FUSED>(r1.x, r1.y, r1.z, ray.dx, ray.dy, ray.dz);
-        dz = row3<FUSED>(r2.x, r2.y, r2.z, ray.dx, ray.dy, ray.dz);
-    } else {
-        dx = row4<FUSED>(r0.x, r0.y, r0.z, r0.w, ray.dx, ray.dy, ray.dz, ray.dw);
-        dy = row4<FUSED>(r1.x, r1.y, r1.z, r1.w, ray.dx, ray.dy, ray.dz, ray.dw);
-        dz = row4<FUSED>(r2.x, r2.y, r2.z, r2.w, ray.dx, ray.dy, ray.dz, ray.dw);
+__device__ __forceinline__ void pair_object_space(const HotPair& h, const RaySplat& r, f2& sx, f2& sy, f2& sz, f2& dx,
+                                                  f2& dy, f2& dz) {
+    sx = h.m[1] * r.sy; sx = fma2_<FUSED>(h.m[0], r.sx, sx); sx = fma2_<FUSED>(h.m[2], r.sz, sx); sx = fma2_<FUSED>(h.m[3], r.sw, sx);
+    sy = h.m[5] * r.sy; sy = fma2_<FUSED>(h.m[4], r.sx, sy); sy = fma2_<FUSED>(h.m[6], r.sz, sy); sy = fma2_<FUSED>(h.m[7], r.sw, sy);
+    sz = h.m[9] * r.sy; sz = fma2_<FUSED>(h.m[8], r.sx, sz); sz = fma2_<FUSED>(h.m[10], r.sz, sz); sz = fma2_<FUSED>(h.m[11], r.sw, sz);
+    dx = h.m[1] * r.dy; dx = fma2_<FUSED>(h.m[0], r.dx, dx); dx = fma2_<FUSED>(h.m[2], r.dz, dx);
+    dy = h.m[5] * r.dy; dy = fma2_<FUSED>(h.m[4], r.dx, dy); dy = fma2_<FUSED>(h.m[6], r.dz, dy);
+    dz = h.m[9] * r.dy; dz = fma2_<FUSED>(h.m[8], r.dx, dz); dz = fma2_<FUSED>(h.m[10], r.dz, dz);
+    if constexpr (!DW0) {
+        dx = fma2_<FUSED>(h.m[3], r.dw, dx);
+        dy = fma2_<FUSED>(h.m[7], r.dw, dy);
+        dz = fma2_<FUSED>(h.m[11], r.dw, dz);
     }
 }
 
-// ---- traversal -------------------------------------------------------------------------------------------
-// Closest hit over objects [0,n) in ascending index order with the reference's tie rules (Q3): a sphere
-// replaces the current hit unless `time < t` (later sphere wins ties), a box unless `time <= t` (earlier
-// wins). `k` is wave-uniform, so the HotObject loads are scalar.
-template <bool FUSED, bool DW0>
-__device__ __forceinline__ void closest_hit(const HotObject* __restrict__ hot, uint32_t n, const Ray& ray, float& T,
-                                            int& index) {
-    for (uint32_t k = 0; k < n; ++k) {
-        const HotObject* o = hot + k;
-        const float4 r0 = o->row0, r1 = o->row1, r2 = o->row2;
-        const uint32_t type = o->type;
-        float sx, sy, sz, dx, dy, dz, t;
-        to_object_space<FUSED, DW0>(r0, r1, r2, ray, sx, sy, sz, dx, dy, dz);
-        if (type == 0u) {
-            if (sphere_candidate<FUSED>(sx, sy, sz, dx, dy, dz, t)) {
-                if (!(T < t)) { T = t; index = (int)k; }
-            }
-        } else if (type == 1u) {
-            if (box_candidate(sx, sy, sz, dx, dy, dz, t)) {
-                if (!(T <= t)) { T = t; index = (int)k; }
-            }
+// the reference's `radical` (shade_and_reflect_kernel.cl:85-94) for both spheres of a pair
+template <bool FUSED>
+__device__ __forceinline__ f2 pair_radical(f2 sx, f2 sy, f2 sz, f2 dx, f2 dy, f2 dz) {
+    f2 A = dy * dy; A = fma2_<FUSED>(dx, dx, A); A = fma2_<FUSED>(dz, dz, A);
+    f2 B = sy * dy; B = fma2_<FUSED>(dx, sx, B); B = fma2_<FUSED>(dz, sz, B); B = B * 2.0f;
+    f2 C = sy * sy; C = fma2_<FUSED>(sx, sx, C); C = fma2_<FUSED>(sz, sz, C); C = C + -1.0f;
+    return fma2_<FUSED>(B, B, (A * 4.0f) * (-C));
+}
+
+// one object of a pair, generic type, on an object-space ray: closest-hit update with the reference's tie rules
+template <bool FUSED>
+__device__ __forceinline__ void closest_update(uint32_t type, float sx, float sy, float sz, float dx, float dy, float dz,
+                                               int k, float& T, int& index) {
+    float t;
+    if (type == 0u) {
+        if (sphere_candidate<FUSED>(sx, sy, sz, dx, dy, dz, t)) {
+            if (!(T < t)) { T = t; index = k; }   // ties: the later sphere wins (Q3)
+        }
+    } else if (type == 1u) {
+        if (box_candidate(sx, sy, sz, dx, dy, dz, t)) {
+            if (!(T <= t)) { T = t; index = k; }  // ties: the earlier object wins (Q3)
         }
     }
 }
 
-// Any accepted candidate with t < 1 (shadow rays; direction = un-normalised light vector, so t in [0,1)
-// means an occluder between the point and the light, shade_and_reflect_kernel.cl:201-209,229).
-template <bool FUSED>
-__device__ __forceinline__ bool any_hit_before_one(const HotObject* __restrict__ hot, uint32_t n, const Ray& ray) {
-    bool occluded = false;
-    for (uint32_t k = 0; k < n; ++k) {
-        const HotObject* o = hot + k;
-        const float4 r0 = o->row0, r1 = o->row1, r2 = o->row2;
-        const uint32_t type = o->type;
-        float sx, sy, sz, dx, dy, dz, t;
-        to_object_space<FUSED, true>(r0, r1, r2, ray, sx, sy, sz, dx, dy, dz);
-        bool cand = false;
-        if (type == 0u) cand = sphere_candidate<FUSED>(sx, sy, sz, dx, dy, dz, t);
-        else if (type == 1u) cand = box_candidate(sx, sy, sz, dx, dy, dz, t);
-        if (cand && t < 1.f) { occluded = true; break; }
+template <bool FUSED, bool DW0>
+__device__ __forceinline__ void closest_pair(const HotPair& h, int p, const RaySplat& r, float& T, int& index) {
+    f2 sx, sy, sz, dx, dy, dz;
+    pair_object_space<FUSED, DW0>(h, r, sx, sy, sz, dx, dy, dz);
+    if ((h.type_a | h.type_b) == 0u) {  // two spheres: packed discriminant filter
+        const f2 rad = pair_radical<FUSED>(sx, sy, sz, dx, dy, dz);
+        const bool ca = !(rad.x < 0), cb = !(rad.y < 0);
+        if (ca || cb) {
+            if (ca) closest_update<FUSED>(0u, sx.x, sy.x, sz.x, dx.x, dy.x, dz.x, 2 * p, T, index);
+            if (cb) closest_update<FUSED>(0u, sx.y, sy.y, sz.y, dx.y, dy.y, dz.y, 2 * p + 1, T, index);
+        }
+    } else {
+        closest_update<FUSED>(h.type_a, sx.x, sy.x, sz.x, dx.x, dy.x, dz.x, 2 * p, T, index);
+        closest_update<FUSED>(h.type_b, sx.y, sy.y, sz.y, dx.y, dy.y, dz.y, 2 * p + 1, T, index);
     }
+}
+
+// L2 warm-up for the pair stream. Scalar loads go K$ -> L2 -> Infinity Cache / HBM; a 100k-object stream
+// (6.4 MB) does not fit one XCD's 4 MB L2 and every wave walks it at the same pace, so without help each pair
+// costs one ~900-cycle miss per wave (measured: 20 ms for ONE wave over 50k pairs). Every 32 pairs each lane
+// therefore touches one 64-B line of the stream kWarmAhead pairs ahead with an ordinary vector load (64 lanes
+// x 64 B = 32 pairs); the value is only xor-ed into a sink one period later, so the wait lands long after the
+// data has arrived. The scalar loads of the traversal then hit L2.
+constexpr uint32_t kWarmPeriod = 32;   // pairs covered by one wave-wide touch
+constexpr uint32_t kWarmAhead = 128;   // pairs of look-ahead
+
+struct Warm {
+    uint32_t pending = 0, sink = 0;
+};
+
+__device__ __forceinline__ void l2_warm(const HotPair* __restrict__ pairs, uint32_t n_pairs, uint32_t p, Warm& w) {
+    w.sink ^= w.pending;  // consumes the touch issued one period ago (long since landed)
+    uint32_t line = (p + kWarmAhead) * 2u + (__lane_id() & 63u);  // 64-B lines, two per pair
+    const uint32_t last = n_pairs * 2u - 1u;
+    line = line < last ? line : last;                              // clamp instead of branching
+    w.pending = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(pairs) + (uint64_t)line * 64u);
+}
+__device__ __forceinline__ void l2_warm_finish(Warm& w) {
+    asm volatile("" ::"v"(w.sink ^ w.pending));  // keep the touches alive; nothing is computed from them
+}
+
+// Closest hit over all objects in ascending index order (the reference's raycast(), :72-177, keeping only
+// (t, index)). Two pair records are kept in flight: the next one is requested before the current one is used.
+template <bool FUSED, bool DW0>
+__device__ __forceinline__ void closest_hit(const HotPair* __restrict__ pairs, uint32_t n_pairs, const Ray& ray, float& T,
+                                            int& index) {
+    if (n_pairs == 0) return;
+    const RaySplat r = splat(ray);
+    Warm warm;
+    HotPair a = pairs[0];
+    uint32_t p = 0;
+    for (; p + 1 < n_pairs; p += 2) {
+        if ((p & (kWarmPeriod - 1u)) == 0u) l2_warm(pairs, n_pairs, p, warm);
+        const HotPair b = pairs[p + 1];
+        closest_pair<FUSED, DW0>(a, (int)p, r, T, index);
+        a = pairs[(p + 2 < n_pairs) ? p + 2 : p + 1];
+        closest_pair<FUSED, DW0>(b, (int)p + 1, r, T, index);
+    }
+    if (p < n_pairs) closest_pair<FUSED, DW0>(a, (int)p, r, T, index);
+    l2_warm_finish(warm);
+}
+
+template <bool FUSED>
+__device__ __forceinline__ bool occludes(uint32_t type, float sx, float sy, float sz, float dx, float dy, float dz) {
+    float t;
+    bool cand = false;
+    if (type == 0u) cand = sphere_candidate<FUSED>(sx, sy, sz, dx, dy, dz, t);
+    else if (type == 1u) cand = box_candidate(sx, sy, sz, dx, dy, dz, t);
+    return cand && t < 1.f;
+}
+
+template <bool FUSED>
+__device__ __forceinline__ bool any_hit_pair(const HotPair& h, const RaySplat& r) {
+    f2 sx, sy, sz, dx, dy, dz;
+    pair_object_space<FUSED, true>(h, r, sx, sy, sz, dx, dy, dz);
+    bool occ = false;
+    if ((h.type_a | h.type_b) == 0u) {
+        const f2 rad = pair_radical<FUSED>(sx, sy, sz, dx, dy, dz);
+        const bool ca = !(rad.x < 0), cb = !(rad.y < 0);
+        if (ca || cb) {
+            if (ca) occ = occludes<FUSED>(0u, sx.x, sy.x, sz.x, dx.x, dy.x, dz.x);
+            if (cb && !occ) occ = occludes<FUSED>(0u, sx.y, sy.y, sz.y, dx.y, dy.y, dz.y);
+        }
+    } else {
+        occ = occludes<FUSED>(h.type_a, sx.x, sy.x, sz.x, dx.x, dy.x, dz.x);
+        if (!occ) occ = occludes<FUSED>(h.type_b, sx.y, sy.y, sz.y, dx.y, dy.y, dz.y);
+    }
+    return occ;
+}
+
+// Any accepted candidate with t < 1 (shadow rays; direction = un-normalised light vector, so t in [0,1)
+// means an occluder between the point and the light, shade_and_reflect_kernel.cl:201-209,229). The loop stays
+// wave-uniform (no per-lane break: lanes that already found their occluder just ride along) and the wave
+// leaves as soon as every active lane has one.
+template <bool FUSED>
+__device__ __forceinline__ bool any_hit_before_one(const HotPair* __restrict__ pairs, uint32_t n_pairs, const Ray& ray) {
+    if (n_pairs == 0) return false;
+    const RaySplat r = splat(ray);
+    bool occluded = false;
+    Warm warm;
+    HotPair a = pairs[0];
+    uint32_t p = 0;
+    for (; p + 1 < n_pairs; p += 2) {
+        if ((p & (kWarmPeriod - 1u)) == 0u) l2_warm(pairs, n_pairs, p, warm);
+        const HotPair b = pairs[p + 1];
+        occluded |= any_hit_pair<FUSED>(a, r);
+        a = pairs[(p + 2 < n_pairs) ? p + 2 : p + 1];
+        occluded |= any_hit_pair<FUSED>(b, r);
+        if (__ballot(!occluded) == 0ull) break;  // wave-uniform exit
+    }
+    if (p < n_pairs && (n_pairs & 1u) && __ballot(!occluded) != 0ull) occluded |= any_hit_pair<FUSED>(a, r);
+    l2_warm_finish(warm);
     return occluded;
 }
 
@@ -286,7 +420,9 @@ __device__ __forceinline__ void materialise(const HotObject* __restrict__ hot, c
 
 // ---- shading -----------------------------------------------------------------------------------------------
 struct Scene {
-    const HotObject* __restrict__ hot;
+    const HotPair* __restrict__ pairs;   // traversal stream, ceil(n_objs / 2) records
+    uint32_t n_pairs;
+    const HotObject* __restrict__ hot;   // per-object rows, read by materialise() only
     const ColdObject* __restrict__ cold;
     const LightRec* __restrict__ lights;
     uint32_t n_objs;
@@ -332,10 +468,10 @@ __device__ __forceinline__ bool light_visible(const Scene& S, const Ray& shadow,
     if (S.literal) {
         float T = kMaxFloat;
         int idx = -1;
-        closest_hit<FUSED, true>(S.hot, S.n_objs, shadow, T, idx);
+        closest_hit<FUSED, true>(S.pairs, S.n_pairs, shadow, T, idx);
         return (T >= 1.f || T < 0);
     }
-    return !any_hit_before_one<FUSED>(S.hot, S.n_objs, shadow);
+    return !any_hit_before_one<FUSED>(S.pairs, S.n_pairs, shadow);
 }
 
 // The light loop in the reference's order. ACCUMULATE: shade_kernel.cl:252 (sum over lights);
@@ -465,7 +601,7 @@ __device__ __forceinline__ void shade_and_reflect_pixel(const Scene& S, uint32_t
         if constexpr (COUNT) ctr.traced += 1;
         float T = kMaxFloat;
         int idx = -1;
-        closest_hit<FUSED, true>(S.hot, S.n_objs, ray, T, idx);
+        closest_hit<FUSED, true>(S.pairs, S.n_pairs, ray, T, idx);
         if (T == kMaxFloat) break;  // raycast() returned false (:173)
         if (!absorbing) break;
         HitRec rh;

@@ -25,4 +25,19 @@ struct RenderParams {
 
 hipError_t launch_render(const RenderParams& p, int kernel, bool fused, bool count, hipStream_t stream);
 
+// large-N path (rt_wavefront.hip): traversal and shading as separate kernels, pixel state in HBM
+struct WavefrontBuffers {
+    float* state = nullptr;                        // wavefront_state_bytes(n_local)
+    uint32_t* q_closest[2] = {nullptr, nullptr};   // wavefront_queue_bytes(n_local) each
+    uint32_t* q_any[2] = {nullptr, nullptr};
+    uint32_t* counts = nullptr;                    // 2 x uint32 device counters
+    uint32_t* h_counts = nullptr;                  // 2 x uint32 pinned host mirror
+    uint64_t capacity = 0;                         // n_local the buffers were sized for
+};
+size_t wavefront_state_bytes(uint64_t n_local);
+size_t wavefront_queue_bytes(uint64_t n_local);
+// Runs a whole frame; synchronises `stream` once per round (to size the next round's launches).
+hipError_t launch_wavefront(const RenderParams& p, int kernel, bool fused, bool count, WavefrontBuffers& buf,
+                            hipStream_t stream, uint32_t* rounds_out);
+
 }  // namespace rt

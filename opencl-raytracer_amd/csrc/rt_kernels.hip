@@ -56,8 +56,8 @@ __global__ __launch_bounds__(256) void render_pixels(const RenderParams p) {
         }
 
         const Scene& S = p.scene;
-        if (p.dir_w_zero) closest_hit<FUSED, true>(S.hot, S.n_objs, ray, T, idx);
-        else closest_hit<FUSED, false>(S.hot, S.n_objs, ray, T, idx);
+        if (p.dir_w_zero) closest_hit<FUSED, true>(S.pairs, S.n_pairs, ray, T, idx);
+        else closest_hit<FUSED, false>(S.pairs, S.n_pairs, ray, T, idx);
         if constexpr (COUNT) { ctr.traced += 1; ctr.reference += 1; }
 
         // raycast()'s return value: shade_and_reflect_kernel.cl:173 vs shade_kernel.cl:167 / hittest_kernel.cl:149

@@ -1,0 +1,468 @@
+// rt_wavefront.hip - the large-N path: traversal and shading in separate gfx950 kernels.
+//
+// With thousands of objects a ray spends >99.9 % of its instructions in the object loop. Inside the
+// monolithic per-pixel kernel (rt_kernels.hip) that loop drags the whole shading state along (151 VGPRs -> 3
+// waves per SIMD); as its own kernel it needs 48 VGPRs and runs 1.5-2x faster per ray-object test. So for
+// big scenes a pixel becomes a small resumable state machine whose state lives in HBM (SoA, ~180 B/pixel):
+//
+//   wf_begin    : primary ray of every work-item -> ray slot, queued for a closest-hit trace
+//   wf_trace_*  : lean traversal kernels over a queue of pixel ids (closest hit / any hit with t < 1)
+//   wf_resume   : consumes each pixel's trace result, advances its state machine to the next ray it needs
+//                 (shadow ray of the next light in the scan, or the next reflection ray) or writes the pixel
+//
+// A pixel has at most one ray in flight, so a frame takes (rays on the longest pixel) rounds - about 2+2D.
+// State traffic per round (~0.4 KB/pixel) is noise next to N x 35 VALU instructions per ray. The arithmetic
+// is the same set of device functions as the monolithic kernel (rt_device.h), only the control flow is cut
+// at the traversal calls; tests require both paths to agree bit for bit.
+#include "rt_kernels.h"
+
+#include <cstring>
+
+namespace rt {
+
+// ---- per-pixel state, struct-of-arrays: field f of pixel i at st[f * n + i] ------------------------------------
+enum : uint32_t {
+    F_SX, F_SY, F_SZ, F_SW, F_DX, F_DY, F_DZ, F_DW,          // the ray in flight (also needed to materialise its hit)
+    F_RES_T, F_RES_I,                                          // trace result: t / index, or occluded flag
+    F_PX, F_PY, F_PZ, F_PW, F_NX, F_NY, F_NZ, F_RX, F_RY, F_RZ, F_HIDX,  // hit being shaded
+    F_LI,                                                      // light index of the shadow ray in flight
+    F_AR, F_AG, F_AB, F_DR, F_DG, F_DB, F_SR, F_SG, F_SB,      // light-loop terms carried between rounds
+    F_CR, F_CG, F_CB,                                          // forward (literal / shade kernel) colour
+    F_ABR, F_ABG, F_ABB, F_RR, F_RG, F_RB, F_AP, F_BOUNCES,    // shade_and_reflect pixel state
+    F_PHASE,
+    F_COUNT
+};
+enum : uint32_t { PH_DONE = 0, PH_PRIMARY = 1, PH_SHADOW_PRIMARY = 2, PH_SHADOW_REFLECT = 3, PH_REFLECT = 4 };
+
+struct WfParams {
+    RenderParams rp;
+    float* st;            // F_COUNT x n_local floats
+    uint32_t* q_closest;  // queue of pixel ids waiting for a closest-hit trace (this round)
+    uint32_t* q_any;      // ... for an any-hit trace
+    uint32_t* q_prev_closest;
+    uint32_t* q_prev_any;
+    uint32_t* counts;     // [0] closest next, [1] any next (device counters)
+    uint32_t n_prev_closest, n_prev_any;
+    int kernel;
+    uint32_t count_rays;  // instrumentation on
+};
+
+__device__ __forceinline__ float& F(const WfParams& w, uint32_t f, uint64_t i) { return w.st[(uint64_t)f * w.rp.n_local + i]; }
+__device__ __forceinline__ uint32_t& U(const WfParams& w, uint32_t f, uint64_t i) {
+    return reinterpret_cast<uint32_t*>(w.st)[(uint64_t)f * w.rp.n_local + i];
+}
+
+__device__ __forceinline__ void store_ray(const WfParams& w, uint64_t i, const Ray& r) {
+    F(w, F_SX, i) = r.sx; F(w, F_SY, i) = r.sy; F(w, F_SZ, i) = r.sz; F(w, F_SW, i) = r.sw;
+    F(w, F_DX, i) = r.dx; F(w, F_DY, i) = r.dy; F(w, F_DZ, i) = r.dz; F(w, F_DW, i) = r.dw;
+}
+__device__ __forceinline__ Ray load_ray(const WfParams& w, uint64_t i) {
+    Ray r;
+    r.sx = F(w, F_SX, i); r.sy = F(w, F_SY, i); r.sz = F(w, F_SZ, i); r.sw = F(w, F_SW, i);
+    r.dx = F(w, F_DX, i); r.dy = F(w, F_DY, i); r.dz = F(w, F_DZ, i); r.dw = F(w, F_DW, i);
+    return r;
+}
+__device__ __forceinline__ void store_hit(const WfParams& w, uint64_t i, const HitRec& h) {
+    F(w, F_PX, i) = h.px; F(w, F_PY, i) = h.py; F(w, F_PZ, i) = h.pz; F(w, F_PW, i) = h.pw;
+    F(w, F_NX, i) = h.nx; F(w, F_NY, i) = h.ny; F(w, F_NZ, i) = h.nz;
+    F(w, F_RX, i) = h.rx; F(w, F_RY, i) = h.ry; F(w, F_RZ, i) = h.rz;
+    U(w, F_HIDX, i) = (uint32_t)h.index;
+}
+__device__ __forceinline__ HitRec load_hit(const WfParams& w, uint64_t i) {
+    HitRec h;
+    h.px = F(w, F_PX, i); h.py = F(w, F_PY, i); h.pz = F(w, F_PZ, i); h.pw = F(w, F_PW, i);
+    h.nx = F(w, F_NX, i); h.ny = F(w, F_NY, i); h.nz = F(w, F_NZ, i);
+    h.rx = F(w, F_RX, i); h.ry = F(w, F_RY, i); h.rz = F(w, F_RZ, i);
+    h.index = (int)U(w, F_HIDX, i);
+    return h;
+}
+
+// append pixel i to a queue (wave-aggregated by the compiler: one atomic per wave per call site)
+__device__ __forceinline__ void push(uint32_t* queue, uint32_t* counter, uint64_t i) {
+    const uint32_t slot = atomicAdd(counter, 1u);
+    queue[slot] = (uint32_t)i;
+}
+
+__device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// ---- wf_begin: primary rays --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wf_begin(const WfParams w) {
+    const RenderParams& p = w.rp;
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= p.n_local) return;
+    uint64_t g = i;
+    if (p.world > 1u) {
+        const uint64_t tile = i / p.tile_rays;
+        const uint64_t off = i - tile * p.tile_rays;
+        g = (tile * p.world + p.rank) * p.tile_rays + off;
+    }
+    if (g >= p.n_rays) {  // padding work-item of a ragged last tile
+        if (w.kernel == 0) reinterpret_cast<float*>(p.out)[i] = kMaxFloat;
+        else reinterpret_cast<float4*>(p.out)[i] = make_float4(0.f, 0.f, 0.f, 1.0f);
+        if (p.aux_t) p.aux_t[i] = kMaxFloat;
+        if (p.aux_index) p.aux_index[i] = -1;
+        U(w, F_PHASE, i) = PH_DONE;
+        return;
+    }
+    Ray ray;
+    if (p.pinhole) {
+        const uint32_t gi = (uint32_t)g;
+        const uint32_t row = gi / p.width;
+        const uint32_t col = gi - row * p.width;
+        ray.sx = 0.f; ray.sy = 0.f; ray.sz = 0.f; ray.sw = 1.f;
+        ray.dx = (float)col - p.half_w;
+        ray.dy = (p.height_f - (float)row) - p.half_h;
+        ray.dz = p.z;
+        ray.dw = 0.f;
+    } else {
+        const float4 s = p.rays[2 * g];
+        const float4 d = p.rays[2 * g + 1];
+        ray.sx = s.x; ray.sy = s.y; ray.sz = s.z; ray.sw = s.w;
+        ray.dx = d.x; ray.dy = d.y; ray.dz = d.z; ray.dw = d.w;
+    }
+    store_ray(w, i, ray);
+    U(w, F_PHASE, i) = PH_PRIMARY;
+    push(w.q_closest, &w.counts[0], i);
+}
+
+// ---- lean traversal kernels ----------------------------------------------------------------------------------------
+template <bool FUSED, bool DW0>
+__global__ __launch_bounds__(256) void wf_trace_closest(const WfParams w, uint32_t n_queue) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_queue) return;
+    const uint64_t i = w.q_prev_closest[t];
+    const Ray ray = load_ray(w, i);
+    float T = kMaxFloat;
+    int idx = -1;
+    closest_hit<FUSED, DW0>(w.rp.scene.pairs, w.rp.scene.n_pairs, ray, T, idx);
+    F(w, F_RES_T, i) = T;
+    U(w, F_RES_I, i) = (uint32_t)idx;
+}
+
+template <bool FUSED, bool LITERAL>
+__global__ __launch_bounds__(256) void wf_trace_any(const WfParams w, uint32_t n_queue) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_queue) return;
+    const uint64_t i = w.q_prev_any[t];
+    const Ray ray = load_ray(w, i);
+    bool lit;
+    if constexpr (LITERAL) {  // the reference's full closest hit, then its `time >= 1 || time < 0` test
+        float T = kMaxFloat;
+        int idx = -1;
+        closest_hit<FUSED, true>(w.rp.scene.pairs, w.rp.scene.n_pairs, ray, T, idx);
+        lit = (T >= 1.f || T < 0);
+    } else {
+        lit = !any_hit_before_one<FUSED>(w.rp.scene.pairs, w.rp.scene.n_pairs, ray);
+    }
+    U(w, F_RES_I, i) = lit ? 1u : 0u;
+}
+
+// ---- the resumable pixel -------------------------------------------------------------------------------------------
+struct Ctx {
+    const WfParams& w;
+    uint64_t i;
+    unsigned long long traced, reference, hits;
+};
+
+template <int KERNEL>
+__device__ __forceinline__ void write_pixel(Ctx& c, float r, float g, float b) {
+    reinterpret_cast<float4*>(c.w.rp.out)[c.i] = make_float4(r, g, b, 1.0f);
+    U(c.w, F_PHASE, c.i) = PH_DONE;
+}
+
+// queue the shadow ray of light `li` for the hit `h` (its geometry is recomputed when the result arrives)
+template <bool FUSED>
+__device__ __forceinline__ void emit_shadow(Ctx& c, const HitRec& h, uint32_t li, uint32_t phase) {
+    const Scene& S = c.w.rp.scene;
+    float nvx = h.nx, nvy = h.ny, nvz = h.nz;
+    normalize3(nvx, nvy, nvz);
+    float vvx = -h.px, vvy = -h.py, vvz = -h.pz;
+    normalize3(vvx, vvy, vvz);
+    LightGeom g;
+    light_geometry<FUSED>(S.lights[li], h, nvx, nvy, nvz, vvx, vvy, vvz, g);
+    store_ray(c.w, c.i, g.shadow);
+    U(c.w, F_LI, c.i) = li;
+    U(c.w, F_PHASE, c.i) = phase;
+    push(c.w.q_any, &c.w.counts[1], c.i);
+    c.traced += 1;
+}
+
+template <int KERNEL, bool FUSED> __device__ void shade_done(Ctx& c, const HitRec& h, bool primary, float cr, float cg, float cb);
+
+// start shading hit `h` (light loop of shade(), shade_and_reflect_kernel.cl:193): first shadow ray, or done if L == 0
+template <int KERNEL, bool FUSED>
+__device__ __forceinline__ void begin_shade(Ctx& c, const HitRec& h, bool primary) {
+    const Scene& S = c.w.rp.scene;
+    store_hit(c.w, c.i, h);
+    c.reference += S.n_lights;
+    if (S.n_lights == 0) { shade_done<KERNEL, FUSED>(c, h, primary, 0.f, 0.f, 0.f); return; }
+    const bool forward = (KERNEL == 1) || S.literal;
+    F(c.w, F_SR, c.i) = 0.f; F(c.w, F_SG, c.i) = 0.f; F(c.w, F_SB, c.i) = 0.f;
+    F(c.w, F_DR, c.i) = 0.f; F(c.w, F_DG, c.i) = 0.f; F(c.w, F_DB, c.i) = 0.f;
+    F(c.w, F_AR, c.i) = 0.f; F(c.w, F_AG, c.i) = 0.f; F(c.w, F_AB, c.i) = 0.f;
+    F(c.w, F_CR, c.i) = 0.f; F(c.w, F_CG, c.i) = 0.f; F(c.w, F_CB, c.i) = 0.f;
+    emit_shadow<FUSED>(c, h, forward ? 0u : S.n_lights - 1u, primary ? PH_SHADOW_PRIMARY : PH_SHADOW_REFLECT);
+}
+
+// one light-loop iteration, resumed with the visibility of light `li`; mirrors shade_forward /
+// shade_last_light_wins in rt_device.h statement for statement
+template <int KERNEL, bool FUSED>
+__device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
+    const Scene& S = c.w.rp.scene;
+    const uint64_t i = c.i;
+    const HitRec h = load_hit(c.w, i);
+    const uint32_t li = U(c.w, F_LI, i);
+    const bool lit = U(c.w, F_RES_I, i) != 0u;
+    const ColdObject* co = S.cold + h.index;
+    const float4 amb = co->amb_absorb, dif = co->dif_shine, spec = co->spec_type;
+    float nvx = h.nx, nvy = h.ny, nvz = h.nz;
+    normalize3(nvx, nvy, nvz);
+    float vvx = -h.px, vvy = -h.py, vvz = -h.pz;
+    normalize3(vvx, vvy, vvz);
+    const LightRec L = S.lights[li];
+    LightGeom g;
+    light_geometry<FUSED>(L, h, nvx, nvy, nvz, vvx, vvy, vvz, g);
+    float sr = F(c.w, F_SR, i), sg = F(c.w, F_SG, i), sb = F(c.w, F_SB, i);
+    const uint32_t phase = primary ? PH_SHADOW_PRIMARY : PH_SHADOW_REFLECT;
+    const bool forward = (KERNEL == 1) || S.literal;
+    if (forward) {
+        const float ar = amb.x * L.ambient.x, ag = amb.y * L.ambient.y, ab = amb.z * L.ambient.z;
+        float dr, dg, db;
+        if (lit) {
+            const float nd = __builtin_fmaxf(g.nDotL, 0.f);
+            dr = (dif.x * L.diffuse.x) * nd; dg = (dif.y * L.diffuse.y) * nd; db = (dif.z * L.diffuse.z) * nd;
+            if (g.nDotL > 0) {
+                const float pw = powf(g.rDotV, __builtin_fmaxf(dif.w, 1.f));
+                sr = (spec.x * L.specular.x) * pw; sg = (spec.y * L.specular.y) * pw; sb = (spec.z * L.specular.z) * pw;
+            }
+        } else {
+            dr = 0.f; dg = 0.f; db = 0.f;
+            sr = 0.f; sg = 0.f; sb = 0.f;
+        }
+        float cr = F(c.w, F_CR, i), cg = F(c.w, F_CG, i), cb = F(c.w, F_CB, i);
+        if (KERNEL == 1) { cr = ((cr + ar) + dr) + sr; cg = ((cg + ag) + dg) + sg; cb = ((cb + ab) + db) + sb; }
+        else { cr = (ar + dr) + sr; cg = (ag + dg) + sg; cb = (ab + db) + sb; }
+        if (li + 1u < S.n_lights) {
+            F(c.w, F_SR, i) = sr; F(c.w, F_SG, i) = sg; F(c.w, F_SB, i) = sb;
+            F(c.w, F_CR, i) = cr; F(c.w, F_CG, i) = cg; F(c.w, F_CB, i) = cb;
+            emit_shadow<FUSED>(c, h, li + 1u, phase);
+        } else {
+            shade_done<KERNEL, FUSED>(c, h, primary, cr, cg, cb);
+        }
+        return;
+    }
+    // backward scan (shade_last_light_wins)
+    float ar = F(c.w, F_AR, i), ag = F(c.w, F_AG, i), ab = F(c.w, F_AB, i);
+    float dr = F(c.w, F_DR, i), dg = F(c.w, F_DG, i), db = F(c.w, F_DB, i);
+    bool need_specular = true;
+    if (li == S.n_lights - 1u) {
+        ar = amb.x * L.ambient.x; ag = amb.y * L.ambient.y; ab = amb.z * L.ambient.z;
+        if (lit) {
+            const float nd = __builtin_fmaxf(g.nDotL, 0.f);
+            dr = (dif.x * L.diffuse.x) * nd; dg = (dif.y * L.diffuse.y) * nd; db = (dif.z * L.diffuse.z) * nd;
+        }
+    }
+    if (!lit) {
+        need_specular = false;
+    } else if (g.nDotL > 0) {
+        const float pw = powf(g.rDotV, __builtin_fmaxf(dif.w, 1.f));
+        sr = (spec.x * L.specular.x) * pw; sg = (spec.y * L.specular.y) * pw; sb = (spec.z * L.specular.z) * pw;
+        need_specular = false;
+    }
+    if (need_specular && li > 0u) {
+        F(c.w, F_AR, i) = ar; F(c.w, F_AG, i) = ag; F(c.w, F_AB, i) = ab;
+        F(c.w, F_DR, i) = dr; F(c.w, F_DG, i) = dg; F(c.w, F_DB, i) = db;
+        emit_shadow<FUSED>(c, h, li - 1u, phase);
+    } else {
+        shade_done<KERNEL, FUSED>(c, h, primary, (ar + dr) + sr, (ag + dg) + sg, (ab + db) + sb);
+    }
+}
+
+// the tail of shade_and_reflect (:281-284)
+__device__ __forceinline__ void finish_reflect(Ctx& c, bool fused, float abr, float abg, float abb, float rr, float rg,
+                                               float rb, float ap, uint32_t bounces) {
+    if (bounces == 0u && ap < 1.f) {
+        const float wgt = 1.f - ap;
+        if (fused) { abr = fma_<true>(wgt, rr, abr); abg = fma_<true>(wgt, rg, abg); abb = fma_<true>(wgt, rb, abb); }
+        else { abr = fma_<false>(wgt, rr, abr); abg = fma_<false>(wgt, rg, abg); abb = fma_<false>(wgt, rb, abb); }
+    }
+    write_pixel<2>(c, abr, abg, abb);
+}
+
+// top of one iteration of `while (bounces-- > 0 && raycast(...) && absorptionPercent <= 0.999f)` (:268)
+template <bool FUSED>
+__device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr, float abg, float abb, float rr, float rg,
+                                          float rb, float ap, uint32_t bounces) {
+    const Scene& S = c.w.rp.scene;
+    const uint32_t before = bounces;
+    bounces = bounces - 1u;
+    if (!(before > 0u)) { finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces); return; }
+    c.reference += 1;
+    const bool absorbing = (ap <= 0.999f);
+    if (!absorbing && !S.literal) { finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces); return; }
+    Ray ray;
+    reflection_ray<FUSED>(from, ray);
+    store_ray(c.w, c.i, ray);
+    const uint64_t i = c.i;
+    F(c.w, F_ABR, i) = abr; F(c.w, F_ABG, i) = abg; F(c.w, F_ABB, i) = abb;
+    F(c.w, F_RR, i) = rr; F(c.w, F_RG, i) = rg; F(c.w, F_RB, i) = rb;
+    F(c.w, F_AP, i) = ap;
+    U(c.w, F_BOUNCES, i) = bounces;
+    U(c.w, F_PHASE, i) = PH_REFLECT;
+    push(c.w.q_closest, &c.w.counts[0], i);
+    c.traced += 1;
+}
+
+template <int KERNEL, bool FUSED>
+__device__ void shade_done(Ctx& c, const HitRec& h, bool primary, float cr, float cg, float cb) {
+    const Scene& S = c.w.rp.scene;
+    if (KERNEL == 1) { write_pixel<1>(c, cr, cg, cb); return; }
+    const uint64_t i = c.i;
+    if (primary) {
+        // absorbColor = hit.mat.absorption * shade(hit) (:255-256); bounces = MAX_BOUNCES (:258)
+        const float ap = S.cold[h.index].amb_absorb.w;
+        loop_step<FUSED>(c, h, cr * ap, cg * ap, cb * ap, 0.f, 0.f, 0.f, ap, c.w.rp.max_bounces);
+    } else {
+        float ap = F(c.w, F_AP, i);
+        float abr = F(c.w, F_ABR, i), abg = F(c.w, F_ABG, i), abb = F(c.w, F_ABB, i);
+        const float ra = (1.f - ap) * S.cold[h.index].amb_absorb.w;
+        abr = fma_<FUSED>(ra, cr, abr); abg = fma_<FUSED>(ra, cg, abg); abb = fma_<FUSED>(ra, cb, abb);
+        ap = ap + ra;
+        loop_step<FUSED>(c, h, abr, abg, abb, cr, cg, cb, ap, U(c.w, F_BOUNCES, i));
+    }
+}
+
+template <int KERNEL, bool FUSED>
+__global__ __launch_bounds__(256) void wf_resume(const WfParams w) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t total = w.n_prev_closest + w.n_prev_any;
+    Ctx c{w, 0, 0ull, 0ull, 0ull};
+    if (t < total) {
+        const uint64_t i = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
+        c.i = i;
+        const Scene& S = w.rp.scene;
+        const uint32_t phase = U(w, F_PHASE, i);
+        if (phase == PH_PRIMARY) {
+            const float T = F(w, F_RES_T, i);
+            const int idx = (int)U(w, F_RES_I, i);
+            const bool hit = (KERNEL == 2) ? !(T == kMaxFloat) : (T < kMaxFloat);
+            c.traced += 1; c.reference += 1; c.hits += hit ? 1 : 0;
+            if (w.rp.aux_t) w.rp.aux_t[i] = T;
+            if (w.rp.aux_index) w.rp.aux_index[i] = hit ? idx : -1;
+            if (KERNEL == 0) {
+                reinterpret_cast<float*>(w.rp.out)[i] = hit ? T : kMaxFloat;
+                U(w, F_PHASE, i) = PH_DONE;
+            } else if (!hit) {
+                write_pixel<KERNEL>(c, 0.f, 0.f, 0.f);
+            } else {
+                const Ray ray = load_ray(w, i);
+                HitRec h;
+                materialise<FUSED>(S.hot, S.cold, idx, T, ray, h);
+                begin_shade<KERNEL, FUSED>(c, h, true);
+            }
+        } else if (phase == PH_SHADOW_PRIMARY) {
+            resume_shadow<KERNEL, FUSED>(c, true);
+        } else if (phase == PH_SHADOW_REFLECT) {
+            resume_shadow<KERNEL, FUSED>(c, false);
+        } else if (phase == PH_REFLECT) {
+            const float T = F(w, F_RES_T, i);
+            const int idx = (int)U(w, F_RES_I, i);
+            const float ap = F(w, F_AP, i);
+            const uint32_t bounces = U(w, F_BOUNCES, i);
+            const float abr = F(w, F_ABR, i), abg = F(w, F_ABG, i), abb = F(w, F_ABB, i);
+            const float rr = F(w, F_RR, i), rg = F(w, F_RG, i), rb = F(w, F_RB, i);
+            if (T == kMaxFloat || !(ap <= 0.999f)) {  // raycast() false, or the absorption test of the loop condition
+                finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces);
+            } else {
+                const Ray ray = load_ray(w, i);
+                HitRec rh;
+                materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
+                begin_shade<KERNEL, FUSED>(c, rh, false);
+            }
+        }
+    }
+    if (w.count_rays) {
+        const unsigned long long a = wave_sum64(c.traced), b = wave_sum64(c.reference), h = wave_sum64(c.hits);
+        if ((threadIdx.x & 63u) == 0u && (a | b | h)) {
+            atomicAdd(&w.rp.counters->traced, a);
+            atomicAdd(&w.rp.counters->reference, b);
+            atomicAdd(&w.rp.counters->hits, h);
+        }
+    }
+}
+
+// ---- host driver -----------------------------------------------------------------------------------------------------
+static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255u) / 256u)); }
+
+size_t wavefront_state_bytes(uint64_t n_local) { return (size_t)F_COUNT * sizeof(float) * (size_t)n_local; }
+size_t wavefront_queue_bytes(uint64_t n_local) { return sizeof(uint32_t) * (size_t)n_local; }
+
+template <int KERNEL, bool FUSED>
+static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t stream, uint32_t* rounds_out) {
+    hipError_t e;
+    const uint64_t n = w.rp.n_local;
+    uint32_t* q[2][2] = {{buf.q_closest[0], buf.q_any[0]}, {buf.q_closest[1], buf.q_any[1]}};
+    int cur = 0;
+    if ((e = hipMemsetAsync(buf.counts, 0, 2 * sizeof(uint32_t), stream)) != hipSuccess) return e;
+    w.st = buf.state;
+    w.counts = buf.counts;
+    w.q_closest = q[cur][0];
+    w.q_any = q[cur][1];
+    hipLaunchKernelGGL(wf_begin, grid_for(n), dim3(256), 0, stream, w);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    uint32_t rounds = 0;
+    bool first = true;
+    for (;;) {
+        // how many rays did the last stage queue?  (one small D2H + sync per round; a round is >= N x 35 VALU
+        // instructions per ray, so this is noise for the scene sizes this path is used for)
+        if ((e = hipMemcpyAsync(buf.h_counts, buf.counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        const uint32_t nc = buf.h_counts[0], na = buf.h_counts[1];
+        if (nc == 0 && na == 0) break;
+        ++rounds;
+        w.q_prev_closest = q[cur][0];
+        w.q_prev_any = q[cur][1];
+        w.n_prev_closest = nc;
+        w.n_prev_any = na;
+        if (nc) {
+            if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
+            else hipLaunchKernelGGL((wf_trace_closest<FUSED, true>), grid_for(nc), dim3(256), 0, stream, w, nc);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (na) {
+            if (w.rp.scene.literal) hipLaunchKernelGGL((wf_trace_any<FUSED, true>), grid_for(na), dim3(256), 0, stream, w, na);
+            else hipLaunchKernelGGL((wf_trace_any<FUSED, false>), grid_for(na), dim3(256), 0, stream, w, na);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        first = false;
+        cur ^= 1;
+        w.q_closest = q[cur][0];
+        w.q_any = q[cur][1];
+        if ((e = hipMemsetAsync(buf.counts, 0, 2 * sizeof(uint32_t), stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL((wf_resume<KERNEL, FUSED>), grid_for((uint64_t)nc + na), dim3(256), 0, stream, w);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    if (rounds_out) *rounds_out = rounds;
+    return hipSuccess;
+}
+
+hipError_t launch_wavefront(const RenderParams& p, int kernel, bool fused, bool count, WavefrontBuffers& buf,
+                            hipStream_t stream, uint32_t* rounds_out) {
+    WfParams w;
+    std::memset(&w, 0, sizeof(w));
+    w.rp = p;
+    w.kernel = kernel;
+    w.count_rays = count ? 1u : 0u;
+    switch (kernel) {
+        case 0: return fused ? run_wavefront<0, true>(w, buf, stream, rounds_out) : run_wavefront<0, false>(w, buf, stream, rounds_out);
+        case 1: return fused ? run_wavefront<1, true>(w, buf, stream, rounds_out) : run_wavefront<1, false>(w, buf, stream, rounds_out);
+        case 2: return fused ? run_wavefront<2, true>(w, buf, stream, rounds_out) : run_wavefront<2, false>(w, buf, stream, rounds_out);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace rt

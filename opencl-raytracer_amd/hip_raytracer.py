@@ -24,7 +24,7 @@ LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libhip_raytracer.so"
 
 KERNEL_HITTEST, KERNEL_SHADE, KERNEL_SHADE_AND_REFLECT = 0, 1, 2
 KERNELS = {"hittest": 0, "shade": 1, "shade_and_reflect": 2}
-FLAG_UNFUSED, FLAG_LITERAL, FLAG_NO_RAYGEN = 0x1, 0x2, 0x4
+FLAG_UNFUSED, FLAG_LITERAL, FLAG_NO_RAYGEN, FLAG_WAVEFRONT, FLAG_MONOLITHIC = 0x1, 0x2, 0x4, 0x8, 0x10
 
 EXPORTS = [
     "rt_abi_version", "rt_create", "rt_set_camera", "rt_set_shard", "rt_local_rays", "rt_render",
@@ -44,6 +44,7 @@ class RTStats(ctypes.Structure):
         ("rays_traced", ctypes.c_uint64), ("rays_reference", ctypes.c_uint64), ("hit_pixels", ctypes.c_uint64),
         ("last_kernel_ms", ctypes.c_float), ("pinhole", ctypes.c_uint32),
         ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("local_rays", ctypes.c_uint64),
+        ("wavefront", ctypes.c_uint32), ("rounds", ctypes.c_uint32),
     ]
 
 
@@ -108,13 +109,14 @@ class HIPRaytracer:
 
     def __init__(self, objects: np.ndarray, lights: np.ndarray, rays: np.ndarray | None, MAX_BOUNCES: int = 0, *,
                  kernel="shade_and_reflect", device: int = 0, fused: bool = True, literal: bool = False,
-                 raygen: bool = True, camera: tuple[int, int, float] | None = None):
+                 raygen: bool = True, camera: tuple[int, int, float] | None = None, path: str = "auto"):
         self._lib = load_library()
         self._ctx = ctypes.c_void_p()
         objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
         lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
         self.kernel = KERNELS[kernel] if isinstance(kernel, str) else int(kernel)
         flags = (0 if fused else FLAG_UNFUSED) | (FLAG_LITERAL if literal else 0) | (0 if raygen else FLAG_NO_RAYGEN)
+        flags |= {"auto": 0, "wavefront": FLAG_WAVEFRONT, "monolithic": FLAG_MONOLITHIC}[path]
         if rays is not None:
             rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
             n_rays = int(rays.shape[0])
