@@ -8,8 +8,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -34,6 +36,11 @@ struct rt_context {
     uint32_t n_pairs = 0;
     rt::HotObject* d_hot = nullptr;
     rt::ColdObject* d_cold = nullptr;
+    float4* d_bounds = nullptr;            // screen rectangles for the current camera
+    std::vector<double> h_spheres;         // per object: bounding sphere cx, cy, cz, R (R = +inf never cull, -inf never hit)
+    bool rects_dirty = true;
+    uint32_t* d_work_counter = nullptr;    // bundle dispenser of the persistent kernel
+    uint32_t work_counter_value = 0;       // what the device counter holds once all queued launches have run
     rt::LightRec* d_lights = nullptr;
     float4* d_rays = nullptr;
     bool have_rays = false;  // ray buffer uploaded
@@ -133,6 +140,111 @@ void repack_objects(const rt_object_data* objs, uint32_t n, std::vector<rt::HotP
         std::memcpy(&type_bits, &o.type, 4);
         c.spec_type = make_float4(o.mat.specular[0], o.mat.specular[1], o.mat.specular[2], type_bits);
     }
+}
+
+// View-space bounding sphere of what the traversal tests for object o: { x : |A x + b| <= r0 } with A, b the
+// rows x,y,z of mvInverse (the kernels never consult mv for intersection) -> centre -A^-1 b, radius
+// r0 * sigma_max(A^-1) <= r0 * |A^-1|_F. Computed in double, then inflated:
+//   R_eff = R * (1 + 2^-9) + |c| * 2^-9
+// which covers (a) the reference's own rounding: its discriminant accepts rays that pass a sphere at up to
+// sqrt(1 + ~1e-6 (|c|/R)^2) radii, (b) the fp32 rounding of the bundle test. Anything doubtful (singular or
+// non-finite matrices) gets +inf = never culled; unknown primitive types can never be hit = -inf.
+struct Sphere { double x, y, z, r; };
+Sphere make_sphere(double x, double y, double z, double r) { return Sphere{x, y, z, r}; }
+Sphere bounding_sphere(const rt_object_data& o) {
+    const double inf = std::numeric_limits<double>::infinity();
+#define make_float4 make_sphere
+    if (o.type > 1u) return make_float4(0.f, 0.f, 0.f, -inf);
+    const float* m = o.mvInverse;
+    double A[3][3] = {{m[0], m[4], m[8]}, {m[1], m[5], m[9]}, {m[2], m[6], m[10]}};
+    const double b[3] = {m[12], m[13], m[14]};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            if (!std::isfinite(A[i][j]) || !std::isfinite(b[i])) return make_float4(0.f, 0.f, 0.f, inf);
+    const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                       A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    double norm2 = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) norm2 += A[i][j] * A[i][j];
+    if (!(std::fabs(det) > 1e-12 * std::pow(norm2, 1.5))) return make_float4(0.f, 0.f, 0.f, inf);
+    double inv[3][3];
+    inv[0][0] = (A[1][1] * A[2][2] - A[1][2] * A[2][1]) / det;
+    inv[0][1] = (A[0][2] * A[2][1] - A[0][1] * A[2][2]) / det;
+    inv[0][2] = (A[0][1] * A[1][2] - A[0][2] * A[1][1]) / det;
+    inv[1][0] = (A[1][2] * A[2][0] - A[1][0] * A[2][2]) / det;
+    inv[1][1] = (A[0][0] * A[2][2] - A[0][2] * A[2][0]) / det;
+    inv[1][2] = (A[0][2] * A[1][0] - A[0][0] * A[1][2]) / det;
+    inv[2][0] = (A[1][0] * A[2][1] - A[1][1] * A[2][0]) / det;
+    inv[2][1] = (A[0][1] * A[2][0] - A[0][0] * A[2][1]) / det;
+    inv[2][2] = (A[0][0] * A[1][1] - A[0][1] * A[1][0]) / det;
+    double c[3], fro2 = 0;
+    for (int i = 0; i < 3; ++i) {
+        c[i] = -(inv[i][0] * b[0] + inv[i][1] * b[1] + inv[i][2] * b[2]);
+        for (int j = 0; j < 3; ++j) fro2 += inv[i][j] * inv[i][j];
+    }
+    // sigma_max(A^-1)^2 = largest eigenvalue of S = A^-1 A^-T (closed form for a symmetric 3x3; double precision,
+    // then padded by 1e-6 relative and never allowed above the Frobenius bound or below a third of it)
+    double S[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) S[i][j] = inv[i][0] * inv[j][0] + inv[i][1] * inv[j][1] + inv[i][2] * inv[j][2];
+    double lam_max = fro2;
+    {
+        const double q = (S[0][0] + S[1][1] + S[2][2]) / 3.0;
+        const double p1 = S[0][1] * S[0][1] + S[0][2] * S[0][2] + S[1][2] * S[1][2];
+        const double p2 = (S[0][0] - q) * (S[0][0] - q) + (S[1][1] - q) * (S[1][1] - q) + (S[2][2] - q) * (S[2][2] - q) + 2.0 * p1;
+        const double pp = std::sqrt(p2 / 6.0);
+        if (pp > 0 && std::isfinite(pp)) {
+            double Bm[3][3];
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) Bm[i][j] = (S[i][j] - (i == j ? q : 0.0)) / pp;
+            double r = (Bm[0][0] * (Bm[1][1] * Bm[2][2] - Bm[1][2] * Bm[2][1]) - Bm[0][1] * (Bm[1][0] * Bm[2][2] - Bm[1][2] * Bm[2][0]) +
+                        Bm[0][2] * (Bm[1][0] * Bm[2][1] - Bm[1][1] * Bm[2][0])) / 2.0;
+            r = r < -1.0 ? -1.0 : (r > 1.0 ? 1.0 : r);
+            const double lam = q + 2.0 * pp * std::cos(std::acos(r) / 3.0);
+            if (std::isfinite(lam) && lam > 0) lam_max = lam * (1.0 + 1e-6);
+        } else if (pp == 0) {
+            lam_max = q * (1.0 + 1e-6);  // S is a multiple of the identity
+        }
+        if (lam_max > fro2) lam_max = fro2;
+        if (lam_max < fro2 / 3.0) lam_max = fro2 / 3.0;  // lambda_max >= trace / 3 always holds
+    }
+    const double r0 = (o.type == 0u) ? 1.0 : std::sqrt(0.75);
+    const double R = r0 * std::sqrt(lam_max);
+    const double cl = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    const double Reff = R * (1.0 + 1.0 / 512.0) + cl / 512.0;
+    if (!std::isfinite(Reff) || !std::isfinite(cl)) return make_float4(0.f, 0.f, 0.f, inf);
+    return make_float4(c[0], c[1], c[2], Reff);
+#undef make_float4
+}
+
+// Conservative projection of a bounding sphere onto the pinhole image plane, in ray-direction units
+// (direction = (x, y, z), z < 0 fixed): [xmin, xmax] from the two tangent planes that contain the camera's y
+// axis, [ymin, ymax] likewise. Unbounded when the sphere reaches the plane z = 0 through the camera; empty when
+// it lies entirely behind it. Padded by one pixel plus 1e-6 relative before rounding outwards to float.
+float4 screen_rect(const Sphere& s, double z) {
+    const float inf = std::numeric_limits<float>::infinity();
+    const float4 all = make_float4(-inf, inf, -inf, inf), none = make_float4(inf, -inf, inf, -inf);
+    if (s.r == -std::numeric_limits<double>::infinity()) return none;
+    if (!std::isfinite(s.r) || !(z < 0)) return all;
+    if (s.z - s.r >= 0) return none;          // entirely behind the camera: every root is negative
+    if (s.z + s.r >= 0) return all;           // reaches the camera plane: silhouette unbounded
+    auto extent = [&](double cu, float& lo, float& hi) {
+        // tangent planes through the origin containing the other image axis: (z cu - u cz)^2 = R^2 (u^2 + z^2)
+        const double a = s.z * s.z - s.r * s.r, b = -2.0 * z * cu * s.z, c = z * z * (cu * cu - s.r * s.r);
+        const double disc = b * b - 4.0 * a * c;
+        if (!(a > 0) || !(disc >= 0)) { lo = -inf; hi = inf; return; }
+        const double sq = std::sqrt(disc);
+        double u0 = (-b - sq) / (2.0 * a), u1 = (-b + sq) / (2.0 * a);
+        if (u0 > u1) std::swap(u0, u1);
+        u0 -= 1.0 + 1e-6 * std::fabs(u0);
+        u1 += 1.0 + 1e-6 * std::fabs(u1);
+        lo = std::nextafter((float)u0, -inf);
+        hi = std::nextafter((float)u1, inf);
+    };
+    float4 r;
+    extent(s.x, r.x, r.y);
+    extent(s.y, r.z, r.w);
+    return r;
 }
 
 // Is the uploaded ray list bit-for-bit the reference's pinhole grid (OpenCL-Raytracer.cpp:18-26,68-72)?
@@ -239,6 +351,7 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     p.scene.pairs = c->d_pairs;
     p.scene.n_pairs = c->n_pairs;
     p.scene.hot = c->d_hot;
+    p.scene.bounds = c->d_bounds;
     p.scene.cold = c->d_cold;
     p.scene.lights = c->d_lights;
     p.scene.n_objs = c->n_objs;
@@ -257,6 +370,20 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     p.height_f = (float)c->height;
     p.z = c->z;
     p.dir_w_zero = (c->pinhole || c->dir_w_zero) ? 1u : 0u;
+    // 2-D pixel bundles need the grid shape (pinhole mode) and shard tiles made of whole 8-row bands
+    const bool row_tiles = c->world <= 1 || (c->width && c->tile_rays % c->width == 0 && (c->tile_rays / c->width) % 8 == 0);
+    if (c->pinhole && row_tiles && c->n_local % c->width == 0 && c->n_local < 0x7fffffffull) {
+        p.tile2d = 1u;
+        p.bundles_x = (c->width + 7u) / 8u;
+        p.local_rows = (uint32_t)(c->n_local / c->width);
+        p.tile_rows = c->world > 1 ? (uint32_t)(c->tile_rays / c->width) : p.local_rows;
+        if (p.tile_rows == 0) p.tile_rows = 1;
+        p.n_bundles = p.bundles_x * ((p.local_rows + 7u) / 8u);
+        p.tile_cull = (c->n_objs > 0 && c->n_objs <= 64 && c->z < 0.0f && !(c->flags & RT_FLAG_LITERAL)) ? 1u : 0u;
+    } else {
+        if (c->n_local > 0xffffffffull - 64) return fail(c, RT_ERR_INVALID_ARGUMENT, "too many rays for one launch");
+        p.n_bundles = (uint32_t)((c->n_local + 63u) / 64u);
+    }
     p.max_bounces = c->max_bounces;
     p.out = d_out;
     p.aux_t = c->aux_t;
@@ -264,6 +391,17 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     p.counters = c->d_counters;
 
     RT_HIP(c, hipSetDevice(c->device));
+    if (p.tile_cull && c->rects_dirty) {  // screen rectangles of the bounding spheres for this camera
+        std::vector<float4> rects(c->n_objs);
+        for (uint32_t i = 0; i < c->n_objs; ++i)
+            rects[i] = screen_rect(Sphere{c->h_spheres[4 * i], c->h_spheres[4 * i + 1], c->h_spheres[4 * i + 2], c->h_spheres[4 * i + 3]},
+                                   (double)c->z);
+        RT_HIP(c, hipMemcpyAsync(c->d_bounds, rects.data(), sizeof(float4) * c->n_objs, hipMemcpyHostToDevice, stream));
+        RT_HIP(c, hipStreamSynchronize(stream));  // `rects` is pageable host memory
+        c->rects_dirty = false;
+    }
+    p.work_counter = c->d_work_counter;
+    p.work_base = c->work_counter_value;
     if (count) RT_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters), stream));
     const uint32_t slot = c->ev_count % kTimingSlots;
     RT_HIP(c, hipEventRecord(c->ev_begin[slot], stream));
@@ -275,7 +413,9 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
         if (rc) return rc;
         e = rt::launch_wavefront(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, c->wf, stream, &c->last_rounds);
     } else {
-        e = rt::launch_render(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, stream);
+        uint32_t waves = 0;
+        e = rt::launch_render(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, stream, &waves);
+        c->work_counter_value += p.n_bundles + waves;  // where the device counter stands after this launch
     }
     if (e != hipSuccess) return fail_hip(c, e, "kernel launch");
     RT_HIP(c, hipEventRecord(c->ev_end[slot], stream));
@@ -357,6 +497,16 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         // one spare record keeps the arrays non-null for n_objs == 0
         RT_TRY(hipMalloc((void**)&c->d_hot, sizeof(rt::HotObject) * (size_t)(n_objs + 1)));
         RT_TRY(hipMalloc((void**)&c->d_cold, sizeof(rt::ColdObject) * (size_t)(n_objs + 1)));
+        if (n_objs <= 64) {  // per-bundle culling is only used for scenes this small
+            c->h_spheres.resize(4 * (size_t)n_objs);
+            for (uint32_t i = 0; i < n_objs; ++i) {
+                const Sphere sp = bounding_sphere(static_cast<const rt_object_data*>(objs)[i]);
+                c->h_spheres[4 * i] = sp.x; c->h_spheres[4 * i + 1] = sp.y; c->h_spheres[4 * i + 2] = sp.z; c->h_spheres[4 * i + 3] = sp.r;
+            }
+        }
+        RT_TRY(hipMalloc((void**)&c->d_bounds, sizeof(float4) * 65));
+        RT_TRY(hipMalloc((void**)&c->d_work_counter, sizeof(uint32_t)));
+        RT_TRY(hipMemset(c->d_work_counter, 0, sizeof(uint32_t)));
         if (n_objs) {
             RT_TRY(hipMemcpy(c->d_hot, hot.data(), sizeof(rt::HotObject) * n_objs, hipMemcpyHostToDevice));
             RT_TRY(hipMemcpy(c->d_cold, cold.data(), sizeof(rt::ColdObject) * n_objs, hipMemcpyHostToDevice));
@@ -397,6 +547,7 @@ int rt_set_camera(rt_context* c, uint32_t width, uint32_t height, float z) {
     c->width = width;
     c->height = height;
     c->z = z;
+    c->rects_dirty = true;
     return RT_OK;
 }
 
@@ -529,6 +680,8 @@ void rt_destroy(rt_context* c) {
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_hot) (void)hipFree(c->d_hot);
     if (c->d_cold) (void)hipFree(c->d_cold);
+    if (c->d_bounds) (void)hipFree(c->d_bounds);
+    if (c->d_work_counter) (void)hipFree(c->d_work_counter);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->d_out) (void)hipFree(c->d_out);

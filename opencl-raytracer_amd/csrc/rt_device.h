@@ -49,6 +49,18 @@ struct LightRec {    // the reference's 64-byte Light, unchanged
 };
 static_assert(sizeof(HotObject) == 64 && sizeof(ColdObject) == 128 && sizeof(LightRec) == 64, "layout");
 
+// Read-only scene data is addressed through the constant address space: that tells the compiler the bytes
+// cannot change during the kernel, so a wave-uniform address becomes a scalar load (s_load_dwordx4/8/16) even
+// when the kernel has already stored pixels (persistent workgroups loop over many pixel blocks, and stores
+// would otherwise demote every later uniform load to a 64-lane vector load of one address).
+#define RT_CONST __attribute__((address_space(4)))
+typedef float f4 __attribute__((ext_vector_type(4)));
+struct HotObjectC {  // HotObject with native vectors (plain loads from the constant address space)
+    f4 row0, row1, row2;
+    uint32_t type;
+    uint32_t pad[3];
+};
+
 struct Ray {
     float sx, sy, sz, sw;
     float dx, dy, dz, dw;
@@ -160,8 +172,21 @@ __device__ __forceinline__ bool box_slab(float& tmin, float& tmax, float start, 
     return true;
 }
 
+// Cheap rejection before the six IEEE divides of the slab test: if the ray's LINE passes the box centre at
+// more than 1 object unit it cannot touch the box, whose farthest point is sqrt(0.75) = 0.866 away. disc / A
+// = 1 - b^2 for the unit sphere; a box hit needs 1 - b^2 >= 0.25, the rounding error of this expression is
+// ~5e-7 * |s|^2, so with |s|^2 < 1e5 a negative value leaves a >= 5x margin. NaNs fall through to the full test.
+__device__ __forceinline__ bool box_line_misses(float sx, float sy, float sz, float dx, float dy, float dz) {
+    const float ss = sx * sx + sy * sy + sz * sz;
+    const float A = dx * dx + dy * dy + dz * dz;
+    const float B = sx * dx + sy * dy + sz * dz;
+    const float disc = B * B - A * (ss - 1.0f);
+    return ss < 1.0e5f && disc < 0.0f;
+}
+
 // unit box [-0.5,0.5]^3 (shade_and_reflect_kernel.cl:123-144)
 __device__ __forceinline__ bool box_candidate(float sx, float sy, float sz, float dx, float dy, float dz, float& t) {
+    if (box_line_misses(sx, sy, sz, dx, dy, dz)) return false;
     float txMin, txMax, tyMin, tyMax, tzMin, tzMax;
     if (!box_slab(txMin, txMax, sx, dx)) return false;
     if (!box_slab(tyMin, tyMax, sy, dy)) return false;
@@ -371,6 +396,63 @@ __device__ __forceinline__ bool any_hit_before_one(const HotPair* __restrict__ p
     return occluded;
 }
 
+// ---- small scenes: one object at a time, optional per-wave candidate mask -----------------------------------
+// With a handful of objects the pair stream buys nothing (most of the time goes into shading, and the wide
+// loops cost registers there). The monolithic kernel therefore walks HotObject records one by one; `mask`
+// (wave-uniform, bit k = object k may be hit by some ray of this wave) skips objects that the per-tile bounding
+// test (rt_kernels.hip) has ruled out for the whole wave. Object order stays ascending, so the tie rules hold.
+template <bool FUSED, bool DW0>
+__device__ __forceinline__ void object_space_one(const RT_CONST HotObjectC* o, const Ray& ray, float& sx, float& sy,
+                                                 float& sz, float& dx, float& dy, float& dz) {
+    const f4 r0 = o->row0, r1 = o->row1, r2 = o->row2;
+    sx = row4<FUSED>(r0.x, r0.y, r0.z, r0.w, ray.sx, ray.sy, ray.sz, ray.sw);
+    sy = row4<FUSED>(r1.x, r1.y, r1.z, r1.w, ray.sx, ray.sy, ray.sz, ray.sw);
+    sz = row4<FUSED>(r2.x, r2.y, r2.z, r2.w, ray.sx, ray.sy, ray.sz, ray.sw);
+    if constexpr (DW0) {
+        dx = row3<FUSED>(r0.x, r0.y, r0.z, ray.dx, ray.dy, ray.dz);
+        dy = row3<FUSED>(r1.x, r1.y, r1.z, ray.dx, ray.dy, ray.dz);
+        dz = row3<FUSED>(r2.x, r2.y, r2.z, ray.dx, ray.dy, ray.dz);
+    } else {
+        dx = row4<FUSED>(r0.x, r0.y, r0.z, r0.w, ray.dx, ray.dy, ray.dz, ray.dw);
+        dy = row4<FUSED>(r1.x, r1.y, r1.z, r1.w, ray.dx, ray.dy, ray.dz, ray.dw);
+        dz = row4<FUSED>(r2.x, r2.y, r2.z, r2.w, ray.dx, ray.dy, ray.dz, ray.dw);
+    }
+}
+
+template <bool FUSED, bool DW0>
+__device__ __forceinline__ void closest_hit_small(const HotObject* __restrict__ hot_, uint32_t n, bool use_mask, uint64_t mask,
+                                                  const Ray& ray, float& T, int& index) {
+    const RT_CONST HotObjectC* hot = (const RT_CONST HotObjectC*)(hot_);
+    if (use_mask) {
+        while (mask) {
+            const int k = __builtin_ctzll(mask);
+            mask &= mask - 1ull;
+            float sx, sy, sz, dx, dy, dz;
+            object_space_one<FUSED, DW0>(hot + k, ray, sx, sy, sz, dx, dy, dz);
+            closest_update<FUSED>(hot[k].type, sx, sy, sz, dx, dy, dz, k, T, index);
+        }
+    } else {
+        for (uint32_t k = 0; k < n; ++k) {
+            float sx, sy, sz, dx, dy, dz;
+            object_space_one<FUSED, DW0>(hot + k, ray, sx, sy, sz, dx, dy, dz);
+            closest_update<FUSED>(hot[k].type, sx, sy, sz, dx, dy, dz, (int)k, T, index);
+        }
+    }
+}
+
+template <bool FUSED>
+__device__ __forceinline__ bool any_hit_small(const HotObject* __restrict__ hot_, uint32_t n, const Ray& ray) {
+    const RT_CONST HotObjectC* hot = (const RT_CONST HotObjectC*)(hot_);
+    bool occluded = false;
+    for (uint32_t k = 0; k < n; ++k) {
+        float sx, sy, sz, dx, dy, dz;
+        object_space_one<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz);
+        occluded |= occludes<FUSED>(hot[k].type, sx, sy, sz, dx, dy, dz);
+        if (__ballot(!occluded) == 0ull) break;
+    }
+    return occluded;
+}
+
 // ---- hit materialisation (once per finished ray) ---------------------------------------------------------
 // intersection = mv * p, normal = normalize((mv * (n,0)).xyz), reflection = reflect(dir, normal)
 // (shade_and_reflect_kernel.cl:112-118 sphere, :149-165 box, :175)
@@ -422,7 +504,9 @@ __device__ __forceinline__ void materialise(const HotObject* __restrict__ hot, c
 struct Scene {
     const HotPair* __restrict__ pairs;   // traversal stream, ceil(n_objs / 2) records
     uint32_t n_pairs;
-    const HotObject* __restrict__ hot;   // per-object rows, read by materialise() only
+    const HotObject* __restrict__ hot;   // per-object rows: materialise(), and the small-scene traversal
+    const float4* __restrict__ bounds;   // per object (pinhole grids, <= 64 objects): conservative screen rectangle
+                                         // (xmin, xmax, ymin, ymax) in ray-direction units; empty = can never be hit
     const ColdObject* __restrict__ cold;
     const LightRec* __restrict__ lights;
     uint32_t n_objs;
@@ -430,11 +514,33 @@ struct Scene {
     uint32_t literal;  // RT_FLAG_LITERAL
 };
 
+// secondary rays (shadow / reflection; direction.w == 0): pair stream in the wavefront kernels, one object at a
+// time in the monolithic kernel (SMALL)
+template <bool FUSED, bool SMALL>
+__device__ __forceinline__ void closest_secondary(const Scene& S, const Ray& ray, float& T, int& idx) {
+    if constexpr (SMALL) closest_hit_small<FUSED, true>(S.hot, S.n_objs, false, 0ull, ray, T, idx);
+    else closest_hit<FUSED, true>(S.pairs, S.n_pairs, ray, T, idx);
+}
+template <bool FUSED, bool SMALL>
+__device__ __forceinline__ bool any_secondary(const Scene& S, const Ray& ray) {
+    if constexpr (SMALL) return any_hit_small<FUSED>(S.hot, S.n_objs, ray);
+    else return any_hit_before_one<FUSED>(S.pairs, S.n_pairs, ray);
+}
+
 struct LightGeom {
     float nlx, nly, nlz;  // normalised light vector
     float nDotL, rDotV;
     Ray shadow;
 };
+
+// pow(rDotV, fmax(shininess, 1)) (:232). An exponent of exactly 1 (the default material) returns the base:
+// that is what libm's powf returns for every finite x >= 0 (its error is orders of magnitude below half an ulp
+// there), and it saves the ~100-instruction OCML powf.
+__device__ __forceinline__ float specular_power(float rDotV, float shininess) {
+    const float e = __builtin_fmaxf(shininess, 1.f);
+    if (e == 1.f) return rDotV;
+    return powf(rDotV, e);
+}
 
 // everything of one light-loop iteration that does not depend on the shadow test
 // (shade_and_reflect_kernel.cl:194-224)
@@ -468,10 +574,10 @@ __device__ __forceinline__ bool light_visible(const Scene& S, const Ray& shadow,
     if (S.literal) {
         float T = kMaxFloat;
         int idx = -1;
-        closest_hit<FUSED, true>(S.pairs, S.n_pairs, shadow, T, idx);
+        closest_secondary<FUSED, true>(S, shadow, T, idx);
         return (T >= 1.f || T < 0);
     }
-    return !any_hit_before_one<FUSED>(S.pairs, S.n_pairs, shadow);
+    return !any_secondary<FUSED, true>(S, shadow);
 }
 
 // The light loop in the reference's order. ACCUMULATE: shade_kernel.cl:252 (sum over lights);
@@ -500,7 +606,7 @@ __device__ __forceinline__ void shade_forward(const Scene& S, const HitRec& h, f
             const float nd = __builtin_fmaxf(g.nDotL, 0.f);
             dr = (dif.x * L.diffuse.x) * nd; dg = (dif.y * L.diffuse.y) * nd; db = (dif.z * L.diffuse.z) * nd;
             if (g.nDotL > 0) {
-                const float pw = powf(g.rDotV, __builtin_fmaxf(dif.w, 1.f));
+                const float pw = specular_power(g.rDotV, dif.w);
                 sr = (spec.x * L.specular.x) * pw; sg = (spec.y * L.specular.y) * pw; sb = (spec.z * L.specular.z) * pw;
             }
         } else {
@@ -549,7 +655,7 @@ __device__ __forceinline__ void shade_last_light_wins(const Scene& S, const HitR
         if (!lit) {
             need_specular = false;  // zeroed here, nothing later re-assigns it
         } else if (g.nDotL > 0) {
-            const float pw = powf(g.rDotV, __builtin_fmaxf(dif.w, 1.f));
+            const float pw = specular_power(g.rDotV, dif.w);
             sr = (spec.x * L.specular.x) * pw; sg = (spec.y * L.specular.y) * pw; sb = (spec.z * L.specular.z) * pw;
             need_specular = false;
         }
@@ -588,8 +694,7 @@ __device__ __forceinline__ void shade_and_reflect_pixel(const Scene& S, uint32_t
     float abr = cr * ap, abg = cg * ap, abb = cb * ap;
     float rr = 0.f, rg = 0.f, rb = 0.f;  // reflectColor
     uint32_t bounces = max_bounces;
-    Ray ray;
-    reflection_ray<FUSED>(hit, ray);
+    HitRec from = hit;  // the hit whose reflection ray the next iteration casts (built only if it is cast)
     // while (bounces-- > 0 && raycast(...) && absorptionPercent <= 0.999f)      (:268)
     for (;;) {
         const uint32_t before = bounces;
@@ -599,9 +704,11 @@ __device__ __forceinline__ void shade_and_reflect_pixel(const Scene& S, uint32_t
         const bool absorbing = (ap <= 0.999f);
         if (!absorbing && !S.literal) break;  // the reference still casts this ray but never reads the result
         if constexpr (COUNT) ctr.traced += 1;
+        Ray ray;
+        reflection_ray<FUSED>(from, ray);
         float T = kMaxFloat;
         int idx = -1;
-        closest_hit<FUSED, true>(S.pairs, S.n_pairs, ray, T, idx);
+        closest_secondary<FUSED, true>(S, ray, T, idx);
         if (T == kMaxFloat) break;  // raycast() returned false (:173)
         if (!absorbing) break;
         HitRec rh;
@@ -610,7 +717,7 @@ __device__ __forceinline__ void shade_and_reflect_pixel(const Scene& S, uint32_t
         const float ra = (1.f - ap) * S.cold[rh.index].amb_absorb.w;
         abr = fma_<FUSED>(ra, rr, abr); abg = fma_<FUSED>(ra, rg, abg); abb = fma_<FUSED>(ra, rb, abb);
         ap = ap + ra;
-        reflection_ray<FUSED>(rh, ray);
+        from = rh;
     }
     if (bounces == 0u && ap < 1.f) {  // (:281-282)
         const float w = 1.f - ap;

@@ -16,6 +16,14 @@ struct RenderParams {
     uint32_t width;
     float half_w, half_h, height_f, z;
     uint32_t dir_w_zero;              // every primary direction has w == 0 exactly
+    uint32_t tile2d;                  // pinhole + row-tile shards: one 8x8-pixel bundle per wave iteration
+    uint32_t tile_cull;               // per-bundle screen-rectangle test of every object (scene.bounds holds rectangles)
+    uint32_t bundles_x;               // 8-pixel bundle columns per bundle row
+    uint32_t local_rows;              // rows this rank renders
+    uint32_t tile_rows;               // rows per shard tile
+    uint32_t n_bundles;               // 8x8 bundles (tile2d) or 64-ray chunks of this launch
+    uint32_t* work_counter;           // monotonically increasing device counter the waves draw bundles from
+    uint32_t work_base;               // its value at the start of this launch
     uint32_t max_bounces;
     void* out;                        // float4 per work-item (kernels 1,2) or float (kernel 0)
     float* aux_t;                     // optional
@@ -23,7 +31,10 @@ struct RenderParams {
     Counters* counters;               // used by counted launches only
 };
 
-hipError_t launch_render(const RenderParams& p, int kernel, bool fused, bool count, hipStream_t stream);
+// waves_launched: every wave draws exactly one out-of-range ticket from work_counter before it exits, so the
+// counter ends at work_base + n_bundles + waves_launched (the host tracks it instead of resetting it).
+hipError_t launch_render(const RenderParams& p, int kernel, bool fused, bool count, hipStream_t stream,
+                         uint32_t* waves_launched);
 
 // large-N path (rt_wavefront.hip): traversal and shading as separate kernels, pixel state in HBM
 struct WavefrontBuffers {

@@ -236,7 +236,7 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
             const float nd = __builtin_fmaxf(g.nDotL, 0.f);
             dr = (dif.x * L.diffuse.x) * nd; dg = (dif.y * L.diffuse.y) * nd; db = (dif.z * L.diffuse.z) * nd;
             if (g.nDotL > 0) {
-                const float pw = powf(g.rDotV, __builtin_fmaxf(dif.w, 1.f));
+                const float pw = specular_power(g.rDotV, dif.w);
                 sr = (spec.x * L.specular.x) * pw; sg = (spec.y * L.specular.y) * pw; sb = (spec.z * L.specular.z) * pw;
             }
         } else {
@@ -269,7 +269,7 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
     if (!lit) {
         need_specular = false;
     } else if (g.nDotL > 0) {
-        const float pw = powf(g.rDotV, __builtin_fmaxf(dif.w, 1.f));
+        const float pw = specular_power(g.rDotV, dif.w);
         sr = (spec.x * L.specular.x) * pw; sg = (spec.y * L.specular.y) * pw; sb = (spec.z * L.specular.z) * pw;
         need_specular = false;
     }
