@@ -33,6 +33,8 @@ _pkg.load()
 from opencl_raytracer_amd import camera, scene_loader, sharding, synthetic  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz = 7.86e13 fp32 lane-instructions/s (157.3 TFLOP/s FMA)
+SPHERE_TEST_LANE_OPS = 35  # minimal exact ray-sphere rejection test: 19 fma + 12 mul + 4 add
 
 WORKLOADS = {
     # name: (description, scene, W, H, kernel, depth)
@@ -72,6 +74,39 @@ def cpu_baseline(objs, lights, rays, kernel, depth, sample_desc):
             "sample": sample_desc, "seconds": best}
 
 
+def measure_cfg4_window(device_index, edge):
+    """BASELINE configs[3]'s scene (100k spheres, 32 lights, depth 3) on the centred edge x edge window of its
+    4096x4096 ray grid: the large-scene (wavefront) path, reported next to the headline line."""
+    import torch
+    from opencl_raytracer_amd.hip_raytracer import HIPRaytracer
+    desc, objs, lights, W, H, kernel, depth = load_workload("cfg4")
+    rays = camera.crop_rays(W, H, W // 2 - edge // 2, H // 2 - edge // 2, edge, edge)
+    rt = HIPRaytracer(objs, lights, rays, depth, kernel=kernel, device=device_index)
+    out = torch.empty((len(rays), 4), dtype=torch.float32, device=torch.device("cuda", device_index))
+    st = rt.count_rays()
+    rt.render_device(out.data_ptr())
+    torch.cuda.synchronize()
+    rt.timing_reset()
+    t0 = time.perf_counter()
+    steps = 2
+    for _ in range(steps):
+        rt.render_device(out.data_ptr())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ms_sum, n = rt.timing_summary()
+    kernel_ms = ms_sum / max(n, 1)
+    res = {"workload": f"synthetic 100k spheres + 32 lights, centred {edge}x{edge} window of the 4096x4096 grid, depth 3",
+           "value": st.rays_reference / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
+           "rays_reference": int(st.rays_reference), "rays_traced": int(st.rays_traced),
+           "mrays_traced_per_s": st.rays_traced / dt / 1e6, "rounds": int(rt.stats().rounds),
+           "roofline_valu": {"bound": "fp32-valu", "achieved": st.object_tests * SPHERE_TEST_LANE_OPS / (kernel_ms * 1e-3) / 1e12,
+                             "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-instr/s",
+                             "frac": st.object_tests * SPHERE_TEST_LANE_OPS / (kernel_ms * 1e-3) / VALU_PEAK_LANE_OPS,
+                             "object_tests": int(st.object_tests), "tests_per_s": st.object_tests / (kernel_ms * 1e-3)}}
+    rt.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,7 +114,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
     ap.add_argument("--tile-rows", type=int, default=16)
+    ap.add_argument("--crop", type=int, default=512, help="window edge for --workload cfg4crop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary large-scene measurement")
     ap.add_argument("--literal", action="store_true", help="trace every ray the reference traces (no exact eliminations)")
     ap.add_argument("--ray-buffer", action="store_true", help="read primary rays from an uploaded buffer instead of in-kernel generation")
     args = ap.parse_args()
@@ -93,8 +130,15 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # RT_BENCH_BACKEND=gloo + RT_BENCH_ONE_GPU=1 rehearses the N-rank path on a single-GPU box
+        backend = os.environ.get("RT_BENCH_BACKEND", "nccl")
+        if os.environ.get("RT_BENCH_ONE_GPU"):
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     device = torch.device("cuda", local_rank)
@@ -108,7 +152,8 @@ def main():
     z = float(camera.camera_z(H))
     crop = None
     if args.workload == "cfg4crop":
-        crop = (W // 2 - 256, H // 2 - 256, 512, 512)
+        crop = (W // 2 - args.crop // 2, H // 2 - args.crop // 2, args.crop, args.crop)
+        desc = desc.replace("512x512", f"{args.crop}x{args.crop}")
 
     from opencl_raytracer_amd.distributed import ShardedHIPRaytracer
     from opencl_raytracer_amd.hip_raytracer import HIPRaytracer  # noqa: F401
@@ -134,10 +179,12 @@ def main():
 
     # untimed instrumentation pass: ray counts of this rank's tiles
     st = rt.rt.count_rays()
-    counts = torch.tensor([st.rays_reference, st.rays_traced, st.hit_pixels], dtype=torch.int64, device=device)
+    red_dev = device if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
+    counts = torch.tensor([st.rays_reference, st.rays_traced, st.hit_pixels], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(counts)
     rays_ref, rays_act, hit_pixels = (int(x) for x in counts.tolist())
+    st_tests = st.object_tests
 
     def step():
         return rt.Render()
@@ -159,7 +206,11 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms_sum, launches = rt.rt.timing_summary()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    extra = {}
+    if world == 1 and args.workload == "cfg3" and not args.no_extra:
+        extra["cfg4_window"] = measure_cfg4_window(local_rank, 1024)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -197,6 +248,17 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rt::render_pixels",
                          "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if args.workload.startswith("cfg4"):
+            # large scenes are FP32-VALU bound, not HBM bound: report the traversal kernels against
+            # the vector-ALU roofline as well (35 lane-instructions per ray-sphere test, counted tests)
+            tests = int(st_tests)
+            valu = tests * SPHERE_TEST_LANE_OPS / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
+            out["roofline_valu"] = {"bound": "fp32-valu", "achieved": valu / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
+                                    "unit": "T lane-instr/s", "frac": valu / VALU_PEAK_LANE_OPS, "object_tests": tests,
+                                    "tests_per_s": tests / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
+                                    "note": "all kernels of a frame (trace + resume); tests = 2 per object pair visited per ray"}
+        if extra:
+            out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             if crop is not None or args.workload == "cfg4":
                 cx, cy, cw, ch = (W // 2 - 16, H // 2 - 16, 32, 32)

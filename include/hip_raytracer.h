@@ -79,6 +79,8 @@ typedef struct rt_stats_t {
     uint64_t local_rays;      /* work-items this context renders (after rt_set_shard)                          */
     uint32_t wavefront;       /* 1 if the last render used the large-scene (wavefront) path                    */
     uint32_t rounds;          /* trace/resume rounds of the last wavefront render                              */
+    uint64_t object_tests;    /* ray-object tests executed by the traversal kernels in the last counted render
+                                 (large-scene path only; 0 otherwise)                                           */
 } rt_stats_t;
 
 /* Build a raytracer for one GPU.

@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -33,6 +34,7 @@ struct rt_context {
     uint64_t n_rays = 0;
 
     rt::HotPair* d_pairs = nullptr;
+    rt::HotPair* d_shadow_pairs = nullptr;  // the same objects sorted by decreasing size (shadow rays are order-free)
     uint32_t n_pairs = 0;
     rt::HotObject* d_hot = nullptr;
     rt::ColdObject* d_cold = nullptr;
@@ -67,7 +69,7 @@ struct rt_context {
     uint32_t last_rounds = 0;
 
     rt::Counters* d_counters = nullptr;
-    rt::Counters counters = {0, 0, 0};
+    rt::Counters counters = {0, 0, 0, 0};
 
     hipEvent_t ev_begin[kTimingSlots];
     hipEvent_t ev_end[kTimingSlots];
@@ -315,10 +317,30 @@ void free_wavefront(rt_context* c) {
     for (int i = 0; i < 2; ++i) {
         if (b.q_closest[i]) (void)hipFree(b.q_closest[i]);
         if (b.q_any[i]) (void)hipFree(b.q_any[i]);
+        if (b.q_slice[i]) (void)hipFree(b.q_slice[i]);
     }
     if (b.counts) (void)hipFree(b.counts);
     if (b.h_counts) (void)hipHostFree(b.h_counts);
     b = rt::WavefrontBuffers{};
+}
+
+// size proxy for ordering the shadow stream: r0 * |A^-1|_F (an upper bound of the bounding radius)
+double size_proxy(const rt_object_data& o) {
+    if (o.type > 1u) return -1.0;
+    const float* m = o.mvInverse;
+    const double A[3][3] = {{m[0], m[4], m[8]}, {m[1], m[5], m[9]}, {m[2], m[6], m[10]}};
+    const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                       A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    if (!(std::fabs(det) > 0) || !std::isfinite(det)) return 1e300;  // degenerate: test it first
+    double cof2 = 0;  // |adj(A)|_F^2 ; A^-1 = adj / det
+    const int nx[3] = {1, 2, 0}, pv[3] = {2, 0, 1};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const double cf = A[nx[i]][nx[j]] * A[pv[i]][pv[j]] - A[nx[i]][pv[j]] * A[pv[i]][nx[j]];
+            cof2 += cf * cf;
+        }
+    const double r = std::sqrt(cof2) / std::fabs(det) * (o.type == 0u ? 1.0 : 0.8660254037844386);
+    return std::isfinite(r) ? r : 1e300;
 }
 
 int ensure_wavefront(rt_context* c) {
@@ -330,16 +352,18 @@ int ensure_wavefront(rt_context* c) {
     for (int i = 0; i < 2; ++i) {
         RT_HIP(c, hipMalloc((void**)&b.q_closest[i], rt::wavefront_queue_bytes(n)));
         RT_HIP(c, hipMalloc((void**)&b.q_any[i], rt::wavefront_queue_bytes(n)));
+        RT_HIP(c, hipMalloc((void**)&b.q_slice[i], rt::wavefront_queue_bytes(n)));
     }
-    RT_HIP(c, hipMalloc((void**)&b.counts, 2 * sizeof(uint32_t)));
-    RT_HIP(c, hipHostMalloc((void**)&b.h_counts, 2 * sizeof(uint32_t), hipHostMallocDefault));
+    RT_HIP(c, hipMalloc((void**)&b.counts, 4 * sizeof(uint32_t)));
+    RT_HIP(c, hipHostMalloc((void**)&b.h_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    b.shadow_pairs = c->d_shadow_pairs;
     b.capacity = n;
     return RT_OK;
 }
 
 int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     if (c->n_local == 0) {  // empty launch: nothing to render, nothing to time
-        if (count) c->counters = rt::Counters{0, 0, 0};
+        if (count) c->counters = rt::Counters{0, 0, 0, 0};
         c->aux_t = nullptr;
         c->aux_index = nullptr;
         return RT_OK;
@@ -492,8 +516,23 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         repack_objects(static_cast<const rt_object_data*>(objs), n_objs, pairs, hot, cold);
         c->n_pairs = (uint32_t)pairs.size();
         RT_TRY(hipMalloc((void**)&c->d_pairs, sizeof(rt::HotPair) * (pairs.size() + 1)));
-        if (!pairs.empty())
+        RT_TRY(hipMalloc((void**)&c->d_shadow_pairs, sizeof(rt::HotPair) * (pairs.size() + 1)));
+        if (!pairs.empty()) {
             RT_TRY(hipMemcpy(c->d_pairs, pairs.data(), sizeof(rt::HotPair) * pairs.size(), hipMemcpyHostToDevice));
+            // shadow stream: same records, objects ordered by decreasing size (stable), re-paired
+            const rt_object_data* od = static_cast<const rt_object_data*>(objs);
+            std::vector<uint32_t> order(n_objs);
+            std::vector<double> size(n_objs);
+            for (uint32_t i = 0; i < n_objs; ++i) { order[i] = i; size[i] = size_proxy(od[i]); }
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return size[a] > size[b]; });
+            std::vector<rt_object_data> sorted(n_objs);
+            for (uint32_t i = 0; i < n_objs; ++i) sorted[i] = od[order[i]];
+            std::vector<rt::HotPair> spairs;
+            std::vector<rt::HotObject> shot;
+            std::vector<rt::ColdObject> scold;
+            repack_objects(sorted.data(), n_objs, spairs, shot, scold);
+            RT_TRY(hipMemcpy(c->d_shadow_pairs, spairs.data(), sizeof(rt::HotPair) * spairs.size(), hipMemcpyHostToDevice));
+        }
         // one spare record keeps the arrays non-null for n_objs == 0
         RT_TRY(hipMalloc((void**)&c->d_hot, sizeof(rt::HotObject) * (size_t)(n_objs + 1)));
         RT_TRY(hipMalloc((void**)&c->d_cold, sizeof(rt::ColdObject) * (size_t)(n_objs + 1)));
@@ -649,6 +688,7 @@ int rt_get_stats(rt_context* c, rt_stats_t* s) {
     s->local_rays = c->n_local;
     s->wavefront = c->last_wavefront ? 1u : 0u;
     s->rounds = c->last_rounds;
+    s->object_tests = c->counters.tests;
     return RT_OK;
 }
 
@@ -678,6 +718,7 @@ void rt_destroy(rt_context* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
+    if (c->d_shadow_pairs) (void)hipFree(c->d_shadow_pairs);
     if (c->d_hot) (void)hipFree(c->d_hot);
     if (c->d_cold) (void)hipFree(c->d_cold);
     if (c->d_bounds) (void)hipFree(c->d_bounds);

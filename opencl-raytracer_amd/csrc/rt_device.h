@@ -77,6 +77,7 @@ struct Counters {
     unsigned long long traced;     // rays actually issued
     unsigned long long reference;  // rays the reference semantics trace
     unsigned long long hits;       // primary hits
+    unsigned long long tests;      // ray-object tests executed by the wavefront traversal kernels (2 per pair visited)
 };
 
 // ---- arithmetic primitives -----------------------------------------------------------------------------
@@ -376,10 +377,12 @@ __device__ __forceinline__ bool any_hit_pair(const HotPair& h, const RaySplat& r
 // wave-uniform (no per-lane break: lanes that already found their occluder just ride along) and the wave
 // leaves as soon as every active lane has one.
 template <bool FUSED>
-__device__ __forceinline__ bool any_hit_before_one(const HotPair* __restrict__ pairs, uint32_t n_pairs, const Ray& ray) {
+__device__ __forceinline__ bool any_hit_before_one(const HotPair* __restrict__ pairs, uint32_t n_pairs, const Ray& ray,
+                                                   uint32_t* pairs_visited = nullptr) {
+    if (pairs_visited) *pairs_visited = 0;
     if (n_pairs == 0) return false;
     const RaySplat r = splat(ray);
-    bool occluded = false;
+    bool occluded = false, done = false;
     Warm warm;
     HotPair a = pairs[0];
     uint32_t p = 0;
@@ -389,9 +392,12 @@ __device__ __forceinline__ bool any_hit_before_one(const HotPair* __restrict__ p
         occluded |= any_hit_pair<FUSED>(a, r);
         a = pairs[(p + 2 < n_pairs) ? p + 2 : p + 1];
         occluded |= any_hit_pair<FUSED>(b, r);
-        if (__ballot(!occluded) == 0ull) break;  // wave-uniform exit
+        if (__ballot(!occluded) == 0ull) { done = true; p += 2; break; }  // wave-uniform exit
     }
-    if (p < n_pairs && (n_pairs & 1u) && __ballot(!occluded) != 0ull) occluded |= any_hit_pair<FUSED>(a, r);
+    if (!done && p < n_pairs) {  // odd pair count: one record left
+        if (__ballot(!occluded) != 0ull) { occluded |= any_hit_pair<FUSED>(a, r); p = n_pairs; }
+    }
+    if (pairs_visited) *pairs_visited = p;
     l2_warm_finish(warm);
     return occluded;
 }

@@ -41,8 +41,10 @@ struct WavefrontBuffers {
     float* state = nullptr;                        // wavefront_state_bytes(n_local)
     uint32_t* q_closest[2] = {nullptr, nullptr};   // wavefront_queue_bytes(n_local) each
     uint32_t* q_any[2] = {nullptr, nullptr};
-    uint32_t* counts = nullptr;                    // 2 x uint32 device counters
-    uint32_t* h_counts = nullptr;                  // 2 x uint32 pinned host mirror
+    uint32_t* q_slice[2] = {nullptr, nullptr};     // survivors of a shadow slice (ping-pong)
+    const HotPair* shadow_pairs = nullptr;         // size-sorted pair stream (owned by the context)
+    uint32_t* counts = nullptr;                    // 4 x uint32 device counters
+    uint32_t* h_counts = nullptr;                  // 4 x uint32 pinned host mirror
     uint64_t capacity = 0;                         // n_local the buffers were sized for
 };
 size_t wavefront_state_bytes(uint64_t n_local);

@@ -41,7 +41,8 @@ struct WfParams {
     uint32_t* q_any;      // ... for an any-hit trace
     uint32_t* q_prev_closest;
     uint32_t* q_prev_any;
-    uint32_t* counts;     // [0] closest next, [1] any next (device counters)
+    uint32_t* counts;     // [0] closest next, [1] any next, [2] shadow-slice survivors (device counters)
+    const HotPair* shadow_pairs;  // pair stream sorted by decreasing size, for order-free shadow tests
     uint32_t n_prev_closest, n_prev_any;
     int kernel;
     uint32_t count_rays;  // instrumentation on
@@ -141,24 +142,54 @@ __global__ __launch_bounds__(256) void wf_trace_closest(const WfParams w, uint32
     closest_hit<FUSED, DW0>(w.rp.scene.pairs, w.rp.scene.n_pairs, ray, T, idx);
     F(w, F_RES_T, i) = T;
     U(w, F_RES_I, i) = (uint32_t)idx;
+    const unsigned long long lanes = (unsigned long long)__popcll(__ballot(true));
+    if (w.count_rays && (threadIdx.x & 63u) == 0u)  // 2 tests per pair for every ray of the wave
+        atomicAdd(&w.rp.counters->tests, 2ull * w.rp.scene.n_pairs * lanes);
 }
 
-template <bool FUSED, bool LITERAL>
-__global__ __launch_bounds__(256) void wf_trace_any(const WfParams w, uint32_t n_queue) {
+// Literal shadow test: the reference's full closest hit, then its `time >= 1 || time < 0` (:229).
+template <bool FUSED>
+__global__ __launch_bounds__(256) void wf_trace_any_literal(const WfParams w, uint32_t n_queue) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_queue) return;
     const uint64_t i = w.q_prev_any[t];
     const Ray ray = load_ray(w, i);
-    bool lit;
-    if constexpr (LITERAL) {  // the reference's full closest hit, then its `time >= 1 || time < 0` test
-        float T = kMaxFloat;
-        int idx = -1;
-        closest_hit<FUSED, true>(w.rp.scene.pairs, w.rp.scene.n_pairs, ray, T, idx);
-        lit = (T >= 1.f || T < 0);
-    } else {
-        lit = !any_hit_before_one<FUSED>(w.rp.scene.pairs, w.rp.scene.n_pairs, ray);
+    float T = kMaxFloat;
+    int idx = -1;
+    closest_hit<FUSED, true>(w.rp.scene.pairs, w.rp.scene.n_pairs, ray, T, idx);
+    U(w, F_RES_I, i) = (T >= 1.f || T < 0) ? 1u : 0u;
+    const unsigned long long lanes = (unsigned long long)__popcll(__ballot(true));
+    if (w.count_rays && (threadIdx.x & 63u) == 0u)
+        atomicAdd(&w.rp.counters->tests, 2ull * w.rp.scene.n_pairs * lanes);
+}
+
+// Shadow rays, one SLICE of the occluder stream per launch. "Is anything in the way" does not depend on the
+// order the objects are asked in, so shadow rays use their own copy of the pair stream, sorted by decreasing
+// size (big occluders first), cut into slices. A ray that finds an occluder in a slice is finished
+// (visibility 0); only the survivors are queued for the next slice. Every ray thus stops within one slice of
+// its first occluder no matter what the other 63 lanes of its wave are doing - the wave-wide early exit of a
+// single long loop almost never fires, because one lit lane keeps the whole wave going.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void wf_trace_any_slice(const WfParams w, const uint32_t* __restrict__ q_in, uint32_t n_queue,
+                                                          uint32_t pair_lo, uint32_t pair_hi, uint32_t* __restrict__ q_out,
+                                                          uint32_t* __restrict__ out_count, uint32_t first_slice) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_queue) return;
+    const uint32_t i = q_in[t];
+    const Ray ray = load_ray(w, i);
+    uint32_t visited = 0;
+    const bool occluded = any_hit_before_one<FUSED>(w.shadow_pairs + pair_lo, pair_hi - pair_lo, ray, &visited);
+    if (w.count_rays) {  // `visited` is wave-uniform: every lane rides along until the wave leaves
+        const unsigned long long lanes = (unsigned long long)__popcll(__ballot(true));
+        if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true)))
+            atomicAdd(&w.rp.counters->tests, 2ull * visited * lanes);
     }
-    U(w, F_RES_I, i) = lit ? 1u : 0u;
+    if (occluded) {
+        U(w, F_RES_I, i) = 0u;
+    } else {
+        if (first_slice) U(w, F_RES_I, i) = 1u;  // lit unless a later slice says otherwise
+        if (q_out) push(q_out, out_count, i);
+    }
 }
 
 // ---- the resumable pixel -------------------------------------------------------------------------------------------
@@ -395,6 +426,9 @@ __global__ __launch_bounds__(256) void wf_resume(const WfParams w) {
     }
 }
 
+constexpr uint32_t kMinSlicePairs = 2048;
+constexpr uint32_t kMaxSlices = 16;
+
 // ---- host driver -----------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255u) / 256u)); }
 
@@ -407,9 +441,10 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
     const uint64_t n = w.rp.n_local;
     uint32_t* q[2][2] = {{buf.q_closest[0], buf.q_any[0]}, {buf.q_closest[1], buf.q_any[1]}};
     int cur = 0;
-    if ((e = hipMemsetAsync(buf.counts, 0, 2 * sizeof(uint32_t), stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(buf.counts, 0, 3 * sizeof(uint32_t), stream)) != hipSuccess) return e;
     w.st = buf.state;
     w.counts = buf.counts;
+    w.shadow_pairs = buf.shadow_pairs;
     w.q_closest = q[cur][0];
     w.q_any = q[cur][1];
     hipLaunchKernelGGL(wf_begin, grid_for(n), dim3(256), 0, stream, w);
@@ -434,9 +469,32 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (na) {
-            if (w.rp.scene.literal) hipLaunchKernelGGL((wf_trace_any<FUSED, true>), grid_for(na), dim3(256), 0, stream, w, na);
-            else hipLaunchKernelGGL((wf_trace_any<FUSED, false>), grid_for(na), dim3(256), 0, stream, w, na);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (w.rp.scene.literal) {
+                hipLaunchKernelGGL((wf_trace_any_literal<FUSED>), grid_for(na), dim3(256), 0, stream, w, na);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            } else {
+                // slices of >= kMinSlicePairs pairs (amortises each launch's pipeline fill), at most kMaxSlices
+                const uint32_t n_pairs = w.rp.scene.n_pairs;
+                uint32_t n_slices = n_pairs / kMinSlicePairs;
+                n_slices = n_slices < 1u ? 1u : (n_slices > kMaxSlices ? kMaxSlices : n_slices);
+                const uint32_t* q_in = w.q_prev_any;
+                uint32_t n_in = na;
+                for (uint32_t sl = 0; sl < n_slices && n_in; ++sl) {
+                    const uint32_t lo = (uint32_t)((uint64_t)n_pairs * sl / n_slices);
+                    const uint32_t hi = (uint32_t)((uint64_t)n_pairs * (sl + 1) / n_slices);
+                    const bool last = (sl + 1 == n_slices);
+                    uint32_t* q_out = last ? nullptr : buf.q_slice[sl & 1u];
+                    if (!last && (e = hipMemsetAsync(buf.counts + 2, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
+                    hipLaunchKernelGGL((wf_trace_any_slice<FUSED>), grid_for(n_in), dim3(256), 0, stream, w, q_in, n_in, lo, hi,
+                                       q_out, buf.counts + 2, sl == 0 ? 1u : 0u);
+                    if ((e = hipGetLastError()) != hipSuccess) return e;
+                    if (last) break;
+                    if ((e = hipMemcpyAsync(buf.h_counts + 2, buf.counts + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+                    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+                    n_in = buf.h_counts[2];
+                    q_in = q_out;
+                }
+            }
         }
         first = false;
         cur ^= 1;

@@ -34,6 +34,16 @@ class FrameGather:
         """Returns the assembled frame on rank `dst`, None elsewhere."""
         if self.world == 1:
             return self.local[: self.n_rays]
+        backend = dist.get_backend(self.group)
+        if backend == "gloo" and self.local.is_cuda:
+            # rehearsal mode (several ranks sharing one GPU, no RCCL): stage through host memory
+            send = self.local.cpu()
+            if self.rank == self.dst:
+                recv = [torch.empty_like(send) for _ in range(self.world)]
+                dist.gather(send, recv, dst=self.dst, group=self.group)
+                return sharding.assemble_frame([r.to(self.local.device) for r in recv], self.tile_rays, self.n_rays)
+            dist.gather(send, None, dst=self.dst, group=self.group)
+            return None
         if self.rank == self.dst:
             dist.gather(self.local, self.recv, dst=self.dst, group=self.group)
             return sharding.assemble_frame(self.recv, self.tile_rays, self.n_rays)

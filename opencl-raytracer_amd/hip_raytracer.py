@@ -44,7 +44,7 @@ class RTStats(ctypes.Structure):
         ("rays_traced", ctypes.c_uint64), ("rays_reference", ctypes.c_uint64), ("hit_pixels", ctypes.c_uint64),
         ("last_kernel_ms", ctypes.c_float), ("pinhole", ctypes.c_uint32),
         ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("local_rays", ctypes.c_uint64),
-        ("wavefront", ctypes.c_uint32), ("rounds", ctypes.c_uint32),
+        ("wavefront", ctypes.c_uint32), ("rounds", ctypes.c_uint32), ("object_tests", ctypes.c_uint64),
     ]
 
 
