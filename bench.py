@@ -6,8 +6,12 @@
 A step = one frame: every primary ray of the workload through hit-test -> shade -> reflection loop, scene and
 rays resident in HBM before the timed region (rays are regenerated in-kernel from (W,H,z); the framebuffer is
 written to HBM; for N > 1 the step includes the RCCL gather of row-tiles to rank 0).
-Default workload = BASELINE.json configs[2], the single-GPU configuration the metric is quoted on:
-simpleScene, 4096x4096, shade_and_reflect, depth 3.
+
+Default workload, for every N = BASELINE.json configs[3], the configuration the metric ("... at 4096x4096,
+1/2/4/8 GPU") and the north_star target are quoted on: synthetic 100k spheres + 32 lights, 4096x4096,
+shade_and_reflect, depth 3 - it fits one GPU (32 MB of scene) and is the same frame at every N, so the per-N
+values are comparable (strong scaling). At N = 1 the line also carries `extra.cfg3`: BASELINE configs[2]
+(simpleScene 4096x4096 depth 3, the HBM-bound small-scene kernel) with its own HBM roofline.
 
 Prints ONE JSON line (rank 0). `value` is Mrays/s counting the rays the reference semantics trace for the
 frame (primary + shadow + reflection = R_ref, the unit both this backend and the reference are charged for the
@@ -55,11 +59,34 @@ def load_workload(name):
     return desc, objs, lights, W, H, kernel, depth
 
 
+def host_cores():
+    """CPU share this process really has: min(logical CPUs, affinity mask, cgroup cpu.max quota)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                quota = int(txt[0])
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if quota > 0:
+                    n = min(n, max(1, quota // period))
+        except (OSError, ValueError, IndexError):
+            pass
+    return n
+
+
 def cpu_baseline(objs, lights, rays, kernel, depth, sample_desc):
     """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, all host cores."""
     from oracle import oracle
     rs = oracle.Restatement(True)
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     best = None
     t_total = 0.0
     for _ in range(3):
@@ -68,41 +95,46 @@ def cpu_baseline(objs, lights, rays, kernel, depth, sample_desc):
         dt = time.perf_counter() - t0
         t_total += dt
         best = dt if best is None else min(best, dt)
-        if t_total > 20.0:
+        if t_total > 12.0:
             break
     return {"value": res["rays_ref"] / best / 1e6, "unit": "Mrays/s", "cores": int(res["threads"]), "kind": "port",
             "sample": sample_desc, "seconds": best}
 
 
-def measure_cfg4_window(device_index, edge):
-    """BASELINE configs[3]'s scene (100k spheres, 32 lights, depth 3) on the centred edge x edge window of its
-    4096x4096 ray grid: the large-scene (wavefront) path, reported next to the headline line."""
+def measure_cfg3(device_index):
+    """BASELINE configs[2] (simpleScene 4096x4096 shade_and_reflect depth 3): the small-scene kernel, HBM-write bound."""
     import torch
     from opencl_raytracer_amd.hip_raytracer import HIPRaytracer
-    desc, objs, lights, W, H, kernel, depth = load_workload("cfg4")
-    rays = camera.crop_rays(W, H, W // 2 - edge // 2, H // 2 - edge // 2, edge, edge)
-    rt = HIPRaytracer(objs, lights, rays, depth, kernel=kernel, device=device_index)
-    out = torch.empty((len(rays), 4), dtype=torch.float32, device=torch.device("cuda", device_index))
+    desc, objs, lights, W, H, kernel, depth = load_workload("cfg3")
+    z = float(camera.camera_z(H))
+    rt = HIPRaytracer(objs, lights, None, depth, kernel=kernel, camera=(W, H, z), device=device_index)
+    out = torch.empty((W * H, 4), dtype=torch.float32, device=torch.device("cuda", device_index))
     st = rt.count_rays()
-    rt.render_device(out.data_ptr())
+    for _ in range(3):
+        rt.render_device(out.data_ptr())
     torch.cuda.synchronize()
     rt.timing_reset()
+    steps = 20
     t0 = time.perf_counter()
-    steps = 2
     for _ in range(steps):
         rt.render_device(out.data_ptr())
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     ms_sum, n = rt.timing_summary()
     kernel_ms = ms_sum / max(n, 1)
-    res = {"workload": f"synthetic 100k spheres + 32 lights, centred {edge}x{edge} window of the 4096x4096 grid, depth 3",
-           "value": st.rays_reference / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
-           "rays_reference": int(st.rays_reference), "rays_traced": int(st.rays_traced),
-           "mrays_traced_per_s": st.rays_traced / dt / 1e6, "rounds": int(rt.stats().rounds),
-           "roofline_valu": {"bound": "fp32-valu", "achieved": st.object_tests * SPHERE_TEST_LANE_OPS / (kernel_ms * 1e-3) / 1e12,
-                             "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "T lane-instr/s",
-                             "frac": st.object_tests * SPHERE_TEST_LANE_OPS / (kernel_ms * 1e-3) / VALU_PEAK_LANE_OPS,
-                             "object_tests": int(st.object_tests), "tests_per_s": st.object_tests / (kernel_ms * 1e-3)}}
+    alg = 16 * W * H + 320 * len(objs) + 64 * len(lights)
+    traffic = None
+    tf = ROOT / "profiles" / "traffic_cfg3.json"
+    if tf.exists():
+        try:
+            traffic = json.loads(tf.read_text())["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
+    res = {"workload": desc, "value": st.rays_reference / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "rays_reference": int(st.rays_reference), "rays_traced": int(st.rays_traced), "hit_pixels": int(st.hit_pixels),
+           "roofline": {"bound": "hbm", "achieved": alg / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rt::render_pixels<2,true,false>",
+                        "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg}}
     rt.close()
     return res
 
@@ -112,7 +144,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="cfg3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg4", choices=sorted(WORKLOADS))
     ap.add_argument("--tile-rows", type=int, default=16)
     ap.add_argument("--crop", type=int, default=512, help="window edge for --workload cfg4crop")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -145,8 +177,8 @@ def main():
     torch.cuda.set_device(device)
 
     heavy = args.workload in ("cfg4",)
-    steps = args.steps if args.steps is not None else (1 if heavy else 20)
-    warmup = args.warmup if args.warmup is not None else (0 if heavy else 3)
+    steps = args.steps if args.steps is not None else (2 if heavy else 20)
+    warmup = args.warmup if args.warmup is not None else (1 if heavy else 3)
 
     desc, objs, lights, W, H, kernel, depth = load_workload(args.workload)
     z = float(camera.camera_z(H))
@@ -180,11 +212,10 @@ def main():
     # untimed instrumentation pass: ray counts of this rank's tiles
     st = rt.rt.count_rays()
     red_dev = device if (world == 1 or dist.get_backend() == "nccl") else torch.device("cpu")
-    counts = torch.tensor([st.rays_reference, st.rays_traced, st.hit_pixels], dtype=torch.int64, device=red_dev)
+    counts = torch.tensor([st.rays_reference, st.rays_traced, st.hit_pixels, st.object_tests], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(counts)
-    rays_ref, rays_act, hit_pixels = (int(x) for x in counts.tolist())
-    st_tests = st.object_tests
+    rays_ref, rays_act, hit_pixels, tests_total = (int(x) for x in counts.tolist())
 
     def step():
         return rt.Render()
@@ -207,8 +238,8 @@ def main():
     kernel_ms_sum, launches = rt.rt.timing_summary()
 
     extra = {}
-    if world == 1 and args.workload == "cfg3" and not args.no_extra:
-        extra["cfg4_window"] = measure_cfg4_window(local_rank, 1024)
+    if world == 1 and args.workload == "cfg4" and not args.no_extra:
+        extra["cfg3"] = measure_cfg3(local_rank)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
@@ -244,24 +275,29 @@ def main():
                        "literal": bool(args.literal)},
             "rays_reference": rays_ref, "rays_traced": rays_act, "hit_pixels": hit_pixels,
             "mrays_traced_per_s": rays_act * steps / elapsed / 1e6,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rt::render_pixels",
-                         "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes},
         }
+        hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes}
         if args.workload.startswith("cfg4"):
-            # large scenes are FP32-VALU bound, not HBM bound: report the traversal kernels against
-            # the vector-ALU roofline as well (35 lane-instructions per ray-sphere test, counted tests)
-            tests = int(st_tests)
+            # 100k-object frames are FP32-VALU bound by four orders of magnitude in bytes: the
+            # roofline that binds the dominant kernels (rt::wf_trace_closest / wf_trace_any_slice) is the vector ALU.
+            # achieved = counted ray-object tests x 35 lane-instructions (the minimal exact ray-sphere rejection
+            # test) / device time of all kernels of the frame; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.
+            tests = int(tests_total)
             valu = tests * SPHERE_TEST_LANE_OPS / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
-            out["roofline_valu"] = {"bound": "fp32-valu", "achieved": valu / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12,
-                                    "unit": "T lane-instr/s", "frac": valu / VALU_PEAK_LANE_OPS, "object_tests": tests,
-                                    "tests_per_s": tests / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0,
-                                    "note": "all kernels of a frame (trace + resume); tests = 2 per object pair visited per ray"}
+            out["roofline"] = {"bound": "valu", "achieved": valu / 1e12, "peak": VALU_PEAK_LANE_OPS * world / 1e12,
+                               "unit": "T lane-instr/s", "frac": valu / (VALU_PEAK_LANE_OPS * world), "traffic": None,
+                               "kernel": "rt::wf_trace_closest + rt::wf_trace_any_slice (+ wf_resume, wf_begin)",
+                               "kernel_ms": kernel_ms, "object_tests": tests,
+                               "tests_per_s": tests / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0, "hbm": hbm}
+        else:
+            hbm["kernel"] = "rt::render_pixels"
+            out["roofline"] = hbm
         if extra:
             out["extra"] = extra
         if not args.no_cpu_baseline and world == 1:
             if crop is not None or args.workload == "cfg4":
-                cx, cy, cw, ch = (W // 2 - 16, H // 2 - 16, 32, 32)
+                cx, cy, cw, ch = (W // 2 - 32, H // 2 - 32, 64, 64)
                 sample = camera.crop_rays(W, H, cx, cy, cw, ch)
                 sdesc = f"centred {cw}x{ch} window of the {W}x{H} ray grid, same scene"
             else:

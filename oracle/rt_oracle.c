@@ -332,10 +332,14 @@ int rto_render(int kernel, uint32_t max_bounces, uint32_t n_objs, const void* ob
     float* out = (float*)out_;
     uint64_t total_rays = 0;
     int used = 1;
+    int chunk = 64;
 #ifdef _OPENMP
     if (threads <= 0) threads = omp_get_max_threads();
     used = threads;
-#pragma omp parallel for schedule(dynamic, 64) num_threads(threads) reduction(+ : total_rays)
+    /* keep every thread fed even when the sample is a few thousand expensive work-items */
+    if ((uint64_t)chunk * (uint64_t)threads * 8u > count) chunk = (int)(count / ((uint64_t)threads * 8u));
+    if (chunk < 1) chunk = 1;
+#pragma omp parallel for schedule(dynamic, chunk) num_threads(threads) reduction(+ : total_rays)
 #endif
     for (int64_t i = (int64_t)first; i < (int64_t)(first + count); ++i) {
         const float* ray = rays + (uint64_t)i * RAY_STRIDE;
@@ -364,5 +368,6 @@ int rto_render(int kernel, uint32_t max_bounces, uint32_t n_objs, const void* ob
         total_rays += ctr.rays_ref;
     }
     if (rays_ref) *rays_ref = total_rays;
+    (void)chunk;
     return used;
 }

@@ -245,3 +245,38 @@ def test_large_scene_sliced_shadow_stream_vs_oracle(restatement):
         got1 = rt.Render()
         assert rt.count_rays().rays_reference == want1["rays_ref"]
     assert compare_frames(got1, want1["out"]) <= RGB_ATOL
+
+
+def test_config4_scene_window_properties(restatement):
+    """BASELINE config 4's scene (100 000 spheres, 32 lights, depth 3) on windows of its 4096x4096 ray grid:
+    an 8x8 block against the oracle, window-in-window equality, idempotence and shard union."""
+    from opencl_raytracer_amd import synthetic
+    from opencl_raytracer_amd.sharding import assemble_frame
+    objs, lights = synthetic.spheres_and_lights(100_000, 32)
+    W = H = 4096
+    big = camera.crop_rays(W, H, 2048 - 64, 2048 - 64, 128, 128)
+    with hip(objs, lights, big, 3) as rt:
+        a = rt.Render()
+        b = rt.Render()
+        st = rt.count_rays()
+    assert st.wavefront == 1 and st.object_tests > 0
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    a = a.reshape(128, 128, 4)
+    # the inner 32x32 window rendered on its own: same pixels, bit for bit
+    small = camera.crop_rays(W, H, 2048 - 16, 2048 - 16, 32, 32)
+    with hip(objs, lights, small, 3) as rt:
+        s = rt.Render().reshape(32, 32, 4)
+    assert np.array_equal(s.view(np.uint32), a[48:80, 48:80].view(np.uint32))
+    # an 8x8 block against the oracle
+    blk = camera.crop_rays(W, H, 2048 - 4, 2048 - 4, 8, 8)
+    want = restatement[True].render("shade_and_reflect", objs, lights, blk, 3)
+    got = a[60:68, 60:68].reshape(64, 4)
+    assert compare_frames(got, want["out"]) <= RGB_ATOL
+    assert int((want["hit_index"] >= 0).sum()) == 64
+    # shards of the window (2 ranks, 16-row tiles) reassemble to the same frame
+    pieces = []
+    for rank in range(2):
+        with hip(objs, lights, big, 3) as rt:
+            rt.set_shard(128 * 16, rank, 2)
+            pieces.append(rt.Render())
+    assert np.array_equal(assemble_frame(pieces, 128 * 16, 128 * 128).view(np.uint32), a.reshape(-1, 4).view(np.uint32))
