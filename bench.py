@@ -101,6 +101,44 @@ def cpu_baseline(objs, lights, rays, kernel, depth, sample_desc):
             "sample": sample_desc, "seconds": best}
 
 
+def measure_brute_force_window(device_index, edge):
+    """The brute-force traversal (every object for every ray: packed-pair stream, RT_FLAG_NO_GRID) on the centred
+    edge x edge window of the cfg4 grid - the kernel that is measured against the FP32 VALU roofline."""
+    import torch
+    from opencl_raytracer_amd.hip_raytracer import HIPRaytracer
+    desc, objs, lights, W, H, kernel, depth = load_workload("cfg4")
+    if edge >= W:
+        rt = HIPRaytracer(objs, lights, None, depth, kernel=kernel, device=device_index, grid=False,
+                          camera=(W, H, float(camera.camera_z(H))))
+        n_out = W * H
+    else:
+        rays = camera.crop_rays(W, H, W // 2 - edge // 2, H // 2 - edge // 2, edge, edge)
+        rt = HIPRaytracer(objs, lights, rays, depth, kernel=kernel, device=device_index, grid=False)
+        n_out = len(rays)
+    out = torch.empty((n_out, 4), dtype=torch.float32, device=torch.device("cuda", device_index))
+    st = rt.count_rays()  # doubles as the warm-up frame
+    torch.cuda.synchronize()
+    rt.timing_reset()
+    t0 = time.perf_counter()
+    steps = 1 if edge >= W else 2
+    for _ in range(steps):
+        rt.render_device(out.data_ptr())
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    ms_sum, n = rt.timing_summary()
+    kernel_ms = ms_sum / max(n, 1)
+    valu = st.object_tests * SPHERE_TEST_LANE_OPS / (kernel_ms * 1e-3)
+    res = {"workload": ("same frame" if edge >= W else f"same scene, centred {edge}x{edge} window of the 4096x4096 grid") +
+                       ", every object tested for every ray (RT_FLAG_NO_GRID)",
+           "kernel": "rt::wf_trace_closest + rt::wf_trace_any_slice (+ wf_resume, wf_begin)",
+           "value": st.rays_reference / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
+           "bound": "valu", "achieved": valu / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "roofline_unit": "T lane-instr/s",
+           "frac": valu / VALU_PEAK_LANE_OPS, "object_tests": int(st.object_tests),
+           "tests_per_s": st.object_tests / (kernel_ms * 1e-3)}
+    rt.close()
+    return res
+
+
 def measure_cfg3(device_index):
     """BASELINE configs[2] (simpleScene 4096x4096 shade_and_reflect depth 3): the small-scene kernel, HBM-write bound."""
     import torch
@@ -151,6 +189,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary large-scene measurement")
     ap.add_argument("--literal", action="store_true", help="trace every ray the reference traces (no exact eliminations)")
     ap.add_argument("--ray-buffer", action="store_true", help="read primary rays from an uploaded buffer instead of in-kernel generation")
+    ap.add_argument("--no-grid", action="store_true", help="large scenes: test every object for every ray (brute-force traversal, the VALU-roofline kernel)")
     args = ap.parse_args()
 
     import torch
@@ -193,18 +232,18 @@ def main():
     if crop is not None:
         rays = camera.crop_rays(W, H, *crop)
         rt = ShardedHIPRaytracer(objs, lights, rays, depth, kernel=kernel, tile_rows=args.tile_rows, width=crop[2],
-                                 device_index=local_rank, literal=args.literal)
+                                 device_index=local_rank, literal=args.literal, grid=not args.no_grid)
         frame_w, frame_h = crop[2], crop[3]
         ray_source = "buffer"
     elif args.ray_buffer:
         rays = camera.primary_rays(W, H)
         rt = ShardedHIPRaytracer(objs, lights, rays, depth, kernel=kernel, tile_rows=args.tile_rows, width=W,
-                                 device_index=local_rank, literal=args.literal, raygen=False)
+                                 device_index=local_rank, literal=args.literal, raygen=False, grid=not args.no_grid)
         frame_w, frame_h = W, H
         ray_source = "buffer"
     else:
         rt = ShardedHIPRaytracer(objs, lights, None, depth, camera=(W, H, z), kernel=kernel, tile_rows=args.tile_rows,
-                                 device_index=local_rank, literal=args.literal)
+                                 device_index=local_rank, literal=args.literal, grid=not args.no_grid)
         frame_w, frame_h = W, H
         ray_source = "in-kernel pinhole"
     n_rays = rt.n_rays
@@ -279,17 +318,26 @@ def main():
         hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes}
         if args.workload.startswith("cfg4"):
-            # 100k-object frames are FP32-VALU bound by four orders of magnitude in bytes: the
-            # roofline that binds the dominant kernels (rt::wf_trace_closest / wf_trace_any_slice) is the vector ALU.
-            # achieved = counted ray-object tests x 35 lane-instructions (the minimal exact ray-sphere rejection
-            # test) / device time of all kernels of the frame; peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.
+            # 100k-object frames are compute bound by four orders of magnitude in bytes: the roofline
+            # that can bind the traversal kernels is the FP32 vector ALU. achieved = counted ray-object tests x 35
+            # lane-instructions (the minimal exact ray-sphere rejection test) / device time of all kernels of the frame;
+            # peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz per GPU.
             tests = int(tests_total)
             valu = tests * SPHERE_TEST_LANE_OPS / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
+            culled = not (args.no_grid or args.literal)
             out["roofline"] = {"bound": "valu", "achieved": valu / 1e12, "peak": VALU_PEAK_LANE_OPS * world / 1e12,
                                "unit": "T lane-instr/s", "frac": valu / (VALU_PEAK_LANE_OPS * world), "traffic": None,
-                               "kernel": "rt::wf_trace_closest + rt::wf_trace_any_slice (+ wf_resume, wf_begin)",
+                               "kernel": ("rt::wf_trace_closest_grid + rt::wf_trace_any_grid" if culled else
+                                          "rt::wf_trace_closest + rt::wf_trace_any_slice") + " (+ wf_resume, wf_begin)",
                                "kernel_ms": kernel_ms, "object_tests": tests,
                                "tests_per_s": tests / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0, "hbm": hbm}
+            if culled:
+                out["roofline"]["note"] = ("default path = conservative grid culling: ~%.0f candidate tests per ray instead of %d; a divergent "
+                                           "per-lane cell walk with 64-B object gathers from L2, latency bound, far from any roofline by "
+                                           "design - the brute-force traversal kernel it replaces is reported in brute_force") % (
+                                               tests / max(rays_act, 1), len(objs))
+                if world == 1 and not args.no_extra:
+                    out["roofline"]["brute_force"] = measure_brute_force_window(local_rank, 4096)
         else:
             hbm["kernel"] = "rt::render_pixels"
             out["roofline"] = hbm

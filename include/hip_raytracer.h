@@ -66,6 +66,8 @@ typedef enum rt_kernel {
                                   early-out, backward light scan, dead reflection ray). Results are identical */
 #define RT_FLAG_NO_RAYGEN 0x4u /* never replace an uploaded pinhole ray grid by in-kernel generation            */
 #define RT_FLAG_WAVEFRONT  0x8u  /* force the large-scene path (separate traversal / shading kernels)          */
+#define RT_FLAG_NO_GRID    0x20u /* large-scene path: test every object for every ray (no conservative grid culling);
+                                    results are identical, this is the brute-force baseline                  */
 #define RT_FLAG_MONOLITHIC 0x10u /* force the small-scene path (one fused kernel per frame); default: chosen by
                                     object count. Both paths produce identical bits.                          */
 

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <new>
@@ -64,6 +65,13 @@ struct rt_context {
     float* aux_t = nullptr;  // caller-owned device buffers for the next render
     int32_t* aux_index = nullptr;
 
+    rt::GridDesc grid = {};                 // device pointers owned by this context
+    uint32_t* d_grid_cell_start = nullptr;
+    uint32_t* d_grid_entries = nullptr;
+    uint32_t* d_grid_always = nullptr;
+    bool affine_w = true;                   // every mv / mvInverse has bottom row (0,0,0,1) exactly
+    bool primary_w_one = true;              // every uploaded primary ray has start.w == 1
+    double origin_lo[3] = {0, 0, 0}, origin_hi[3] = {0, 0, 0};  // box of the primary ray origins
     rt::WavefrontBuffers wf;
     bool last_wavefront = false;
     uint32_t last_rounds = 0;
@@ -357,6 +365,7 @@ int ensure_wavefront(rt_context* c) {
     RT_HIP(c, hipMalloc((void**)&b.counts, 4 * sizeof(uint32_t)));
     RT_HIP(c, hipHostMalloc((void**)&b.h_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
     b.shadow_pairs = c->d_shadow_pairs;
+    b.grid = c->grid;
     b.capacity = n;
     return RT_OK;
 }
@@ -450,6 +459,124 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     return RT_OK;
 }
 
+// Conservative uniform grid for the large-scene trace kernels (rt_grid.h explains the margins).
+int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
+    c->grid = rt::GridDesc{};
+    if (n == 0 || (c->flags & RT_FLAG_NO_GRID) || !c->affine_w || !c->primary_w_one) return RT_OK;
+    std::vector<Sphere> sph(n);
+    double lo[3] = {c->origin_lo[0], c->origin_lo[1], c->origin_lo[2]};
+    double hi[3] = {c->origin_hi[0], c->origin_hi[1], c->origin_hi[2]};
+    const double inf = std::numeric_limits<double>::infinity();
+    for (uint32_t i = 0; i < n; ++i) {
+        sph[i] = bounding_sphere(objs[i]);  // r already carries the 2^-9 relative margins
+        if (!std::isfinite(sph[i].r)) continue;  // +inf: always-list, -inf: can never be hit
+        const double cc[3] = {sph[i].x, sph[i].y, sph[i].z};
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], cc[a] - sph[i].r);
+            hi[a] = std::max(hi[a], cc[a] + sph[i].r);
+        }
+    }
+    const double ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    const double diag = std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
+    if (!(diag > 0) || !std::isfinite(diag)) return RT_OK;
+    // cell edge: about two cells per object in volume, at most 256 cells per axis
+    double cells_per_object = 4.0;
+    if (const char* env = std::getenv("RT_GRID_CELLS_PER_OBJECT")) {  // tuning knob (results do not depend on it)
+        const double v = std::atof(env);
+        if (v > 0.01 && v < 1000.0) cells_per_object = v;
+    }
+    double cell = std::cbrt(std::max(ext[0], 1e-6) * std::max(ext[1], 1e-6) * std::max(ext[2], 1e-6) / (cells_per_object * n));
+    cell = std::max(cell, std::max(ext[0], std::max(ext[1], ext[2])) / 256.0);
+    if (!(cell > 0) || !std::isfinite(cell)) return RT_OK;
+    // inflated radius per object: sqrt(R^2 + 1e-5 D^2) * 1.001 + 0.01 cell, D = reach of any ray origin
+    std::vector<double> rg(n);
+    std::vector<uint32_t> always;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (sph[i].r == -inf) { rg[i] = -1.0; continue; }
+        if (!std::isfinite(sph[i].r)) { rg[i] = inf; always.push_back(i); continue; }
+        double D2 = 0;
+        const double cc[3] = {sph[i].x, sph[i].y, sph[i].z};
+        for (int a = 0; a < 3; ++a) {
+            const double d = std::max(std::fabs(cc[a] - lo[a]), std::fabs(hi[a] - cc[a]));
+            D2 += d * d;
+        }
+        rg[i] = std::sqrt(sph[i].r * sph[i].r + 1e-5 * D2) * 1.001 + 0.01 * cell;
+        if (rg[i] > 0.25 * diag) { rg[i] = inf; always.push_back(i); }  // as big as the scene: test it for every ray
+    }
+    if (always.size() > 64) return RT_OK;  // a grid would not pay: stay with the brute-force stream
+    // the grid box: everything registered plus the ray origins, padded by one cell
+    double glo[3], ghi[3];
+    for (int a = 0; a < 3; ++a) { glo[a] = lo[a] - cell; ghi[a] = hi[a] + cell; }
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!(rg[i] >= 0) || !std::isfinite(rg[i])) continue;
+        const double cc[3] = {sph[i].x, sph[i].y, sph[i].z};
+        for (int a = 0; a < 3; ++a) { glo[a] = std::min(glo[a], cc[a] - rg[i] - cell); ghi[a] = std::max(ghi[a], cc[a] + rg[i] + cell); }
+    }
+    int dim[3];
+    for (int a = 0; a < 3; ++a) {
+        dim[a] = (int)std::ceil((ghi[a] - glo[a]) / cell);
+        if (dim[a] < 1) dim[a] = 1;
+        if (dim[a] > 320) return RT_OK;
+    }
+    const float cellf = (float)cell;
+    const float lof[3] = {(float)glo[0], (float)glo[1], (float)glo[2]};
+    // cell range of a sphere's box, computed with the SAME float origin / cell edge the kernels use (rg already
+    // contains 0.01 cell of slack for the kernels' fp32 cell arithmetic)
+    auto range = [&](uint32_t i, int a, int& i0, int& i1) {
+        const double cc = (a == 0 ? sph[i].x : a == 1 ? sph[i].y : sph[i].z);
+        i0 = (int)std::floor((cc - rg[i] - (double)lof[a]) / (double)cellf);
+        i1 = (int)std::floor((cc + rg[i] - (double)lof[a]) / (double)cellf);
+        i0 = std::max(i0, 0);
+        i1 = std::min(i1, dim[a] - 1);
+    };
+    const size_t n_cells = (size_t)dim[0] * dim[1] * dim[2];
+    std::vector<uint32_t> start(n_cells + 1, 0);
+    size_t total = 0;
+    std::vector<uint32_t> entries, fill;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            fill.assign(start.begin(), start.end() - 1);
+            entries.assign(total, 0);
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!(rg[i] >= 0) || !std::isfinite(rg[i])) continue;
+            int x0, x1, y0, y1, z0, z1;
+            range(i, 0, x0, x1); range(i, 1, y0, y1); range(i, 2, z0, z1);
+            for (int z = z0; z <= z1; ++z)
+                for (int y = y0; y <= y1; ++y)
+                    for (int x = x0; x <= x1; ++x) {
+                        const size_t cidx = ((size_t)z * dim[1] + y) * dim[0] + x;
+                        if (pass == 0) start[cidx + 1] += 1;
+                        else entries[fill[cidx]++] = i;
+                    }
+        }
+        if (pass == 0) {
+            for (size_t k = 0; k < n_cells; ++k) start[k + 1] += start[k];
+            total = start[n_cells];
+            if (total > 64ull * n + 1024) return RT_OK;  // objects too large for this cell size: not worth it
+        } else {
+            RT_HIP(c, hipMalloc((void**)&c->d_grid_cell_start, sizeof(uint32_t) * (n_cells + 1)));
+            RT_HIP(c, hipMalloc((void**)&c->d_grid_entries, sizeof(uint32_t) * (total + 1)));
+            RT_HIP(c, hipMalloc((void**)&c->d_grid_always, sizeof(uint32_t) * (always.size() + 1)));
+            RT_HIP(c, hipMemcpy(c->d_grid_cell_start, start.data(), sizeof(uint32_t) * (n_cells + 1), hipMemcpyHostToDevice));
+            if (total) RT_HIP(c, hipMemcpy(c->d_grid_entries, entries.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
+            if (!always.empty())
+                RT_HIP(c, hipMemcpy(c->d_grid_always, always.data(), sizeof(uint32_t) * always.size(), hipMemcpyHostToDevice));
+        }
+    }
+    rt::GridDesc& g = c->grid;
+    g.lox = lof[0]; g.loy = lof[1]; g.loz = lof[2];
+    g.cell = cellf;
+    g.inv_cell = 1.0f / cellf;
+    g.nx = dim[0]; g.ny = dim[1]; g.nz = dim[2];
+    g.cell_start = c->d_grid_cell_start;
+    g.entries = c->d_grid_entries;
+    g.always = c->d_grid_always;
+    g.n_always = (uint32_t)always.size();
+    g.enabled = 1u;
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -466,7 +593,7 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
     if (kernel < 0 || kernel > 2) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "kernel must be 0, 1 or 2");
     if ((n_objs && !objs) || (n_lights && !lights))
         return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "objs/lights is NULL with a non-zero count");
-    if (flags & ~(RT_FLAG_UNFUSED | RT_FLAG_LITERAL | RT_FLAG_NO_RAYGEN | RT_FLAG_WAVEFRONT | RT_FLAG_MONOLITHIC))
+    if (flags & ~(RT_FLAG_UNFUSED | RT_FLAG_LITERAL | RT_FLAG_NO_RAYGEN | RT_FLAG_WAVEFRONT | RT_FLAG_MONOLITHIC | RT_FLAG_NO_GRID))
         return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "unknown flag bits");
     if ((flags & RT_FLAG_WAVEFRONT) && (flags & RT_FLAG_MONOLITHIC))
         return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "RT_FLAG_WAVEFRONT and RT_FLAG_MONOLITHIC are exclusive");
@@ -554,6 +681,11 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
     RT_TRY(hipMalloc((void**)&c->d_lights, sizeof(rt::LightRec) * (size_t)(n_lights + 1)));
     if (n_lights) RT_TRY(hipMemcpy(c->d_lights, lights, sizeof(rt::LightRec) * n_lights, hipMemcpyHostToDevice));
 
+    for (uint32_t i = 0; i < n_objs && c->affine_w; ++i) {
+        const rt_object_data& o = static_cast<const rt_object_data*>(objs)[i];
+        c->affine_w = o.mv[3] == 0.f && o.mv[7] == 0.f && o.mv[11] == 0.f && o.mv[15] == 1.f && o.mvInverse[3] == 0.f &&
+                      o.mvInverse[7] == 0.f && o.mvInverse[11] == 0.f && o.mvInverse[15] == 1.f;
+    }
     if (rays && n_rays) {
         const rt_ray* r = static_cast<const rt_ray*>(rays);
         uint32_t W = 0, H = 0;
@@ -567,12 +699,23 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
             bool w0 = true;
             for (uint64_t i = 0; i < n_rays && w0; ++i) w0 = (r[i].direction[3] == 0.0f);
             c->dir_w_zero = w0;
+            for (uint64_t i = 0; i < n_rays; ++i) {  // where do primary rays start? (grid margins need it)
+                if (r[i].start[3] != 1.0f || !std::isfinite(r[i].start[0] + r[i].start[1] + r[i].start[2])) { c->primary_w_one = false; break; }
+                for (int a = 0; a < 3; ++a) {
+                    c->origin_lo[a] = std::min(c->origin_lo[a], (double)r[i].start[a]);
+                    c->origin_hi[a] = std::max(c->origin_hi[a], (double)r[i].start[a]);
+                }
+            }
             RT_TRY(hipMalloc((void**)&c->d_rays, sizeof(rt_ray) * (size_t)n_rays));
             RT_TRY(hipMemcpy(c->d_rays, rays, sizeof(rt_ray) * (size_t)n_rays, hipMemcpyHostToDevice));
             c->have_rays = true;
         }
     }
 #undef RT_TRY
+    if (n_objs >= kWavefrontMinObjects || (flags & RT_FLAG_WAVEFRONT)) {
+        rc = build_grid(c, static_cast<const rt_object_data*>(objs), n_objs);
+        if (rc != RT_OK) return bail(rc);
+    }
     *out_ctx = c;
     return RT_OK;
 }
@@ -723,6 +866,9 @@ void rt_destroy(rt_context* c) {
     if (c->d_cold) (void)hipFree(c->d_cold);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
     if (c->d_work_counter) (void)hipFree(c->d_work_counter);
+    if (c->d_grid_cell_start) (void)hipFree(c->d_grid_cell_start);
+    if (c->d_grid_entries) (void)hipFree(c->d_grid_entries);
+    if (c->d_grid_always) (void)hipFree(c->d_grid_always);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->d_out) (void)hipFree(c->d_out);

@@ -1,0 +1,229 @@
+// rt_grid.h - conservative uniform grid over the objects' bounding spheres, for the large-scene trace kernels.
+//
+// The reference tests every ray against every object. The grid does not change WHAT is computed for an
+// object - a candidate still goes through the reference's exact test on the same object-space ray - it only
+// skips objects that cannot pass that test, so the result (winner index, t, visibility) is bit-identical to
+// the brute-force loops. "Cannot pass" has to hold for the reference's fp32 arithmetic, not for exact geometry:
+// its discriminant B^2 - 4AC carries an absolute error of up to ~40 eps * 4A|o|^2 (o = ray origin in object
+// space), so it can accept a ray whose line passes the unit sphere at b^2 <= 1 + ~2.4e-6 |o|^2. In view space
+// that is a sphere of radius sqrt(R^2 + 2.4e-6 D^2) for a ray that starts D away. The grid therefore registers
+// every object with
+//       R_grid = sqrt(R^2 + 1e-5 * D_k^2) * 1.001 + 0.01 cell
+// where R is the (double-precision, host-computed) radius of its bounding sphere and D_k the largest distance
+// from its centre to any possible ray origin (scene box, camera, uploaded ray origins) - a 4x margin on the
+// error bound - and the walk keeps going for two more cells after the current best hit. Objects whose bounds are
+// not finite or are as large as the scene sit in an "always" list that every ray tests. tests/ compare the grid
+// path with the brute-force path bit for bit (RT_FLAG_NO_GRID forces the latter).
+//
+// Order: cells are visited front to back and objects repeat across cells, so the closest-hit update uses the
+// order-free form of the reference's sequential tie rules (Q3): among the candidates with the smallest t the
+// winner is the highest-index sphere if there is one, else the lowest-index box.
+#pragma once
+
+#include "rt_device.h"
+
+namespace rt {
+
+struct GridDesc {
+    float lox, loy, loz;        // grid origin (view space)
+    float inv_cell;             // 1 / cell edge
+    float cell;                 // cell edge
+    int nx, ny, nz;
+    const uint32_t* __restrict__ cell_start;  // nx*ny*nz + 1 offsets into entries
+    const uint32_t* __restrict__ entries;     // object indices, ascending inside a cell
+    const uint32_t* __restrict__ always;      // objects every ray must test
+    uint32_t n_always;
+    uint32_t enabled;
+};
+
+// order-free closest-hit update (see header comment); `cur_sphere` = the current winner is a sphere
+template <bool FUSED>
+__device__ __forceinline__ void closest_update_unordered(uint32_t type, float sx, float sy, float sz, float dx, float dy,
+                                                         float dz, int k, float& T, int& index, bool& cur_sphere) {
+    float t;
+    bool cand = false;
+    if (type == 0u) cand = sphere_candidate<FUSED>(sx, sy, sz, dx, dy, dz, t);
+    else if (type == 1u) cand = box_candidate(sx, sy, sz, dx, dy, dz, t);
+    if (!cand) return;
+    const bool sphere = (type == 0u);
+    bool take;
+    if (t < T) take = true;
+    else if (t == T) take = sphere ? (!cur_sphere || k > index) : (!cur_sphere && k < index);
+    else take = false;
+    if (take) { T = t; index = k; cur_sphere = sphere; }
+}
+
+// per-lane object test: the HotObject arrives through ordinary (divergent) vector loads
+template <bool FUSED, bool DW0>
+__device__ __forceinline__ void lane_object_space(const HotObject* __restrict__ o, const Ray& ray, float& sx, float& sy,
+                                                  float& sz, float& dx, float& dy, float& dz, uint32_t& type) {
+    const float4 r0 = o->row0, r1 = o->row1, r2 = o->row2;
+    type = o->type;
+    sx = row4<FUSED>(r0.x, r0.y, r0.z, r0.w, ray.sx, ray.sy, ray.sz, ray.sw);
+    sy = row4<FUSED>(r1.x, r1.y, r1.z, r1.w, ray.sx, ray.sy, ray.sz, ray.sw);
+    sz = row4<FUSED>(r2.x, r2.y, r2.z, r2.w, ray.sx, ray.sy, ray.sz, ray.sw);
+    if constexpr (DW0) {
+        dx = row3<FUSED>(r0.x, r0.y, r0.z, ray.dx, ray.dy, ray.dz);
+        dy = row3<FUSED>(r1.x, r1.y, r1.z, ray.dx, ray.dy, ray.dz);
+        dz = row3<FUSED>(r2.x, r2.y, r2.z, ray.dx, ray.dy, ray.dz);
+    } else {
+        dx = row4<FUSED>(r0.x, r0.y, r0.z, r0.w, ray.dx, ray.dy, ray.dz, ray.dw);
+        dy = row4<FUSED>(r1.x, r1.y, r1.z, r1.w, ray.dx, ray.dy, ray.dz, ray.dw);
+        dz = row4<FUSED>(r2.x, r2.y, r2.z, r2.w, ray.dx, ray.dy, ray.dz, ray.dw);
+    }
+}
+
+// 3-D DDA state for one ray. All of it is plain fp32 bookkeeping about WHICH cells to look at; it never feeds
+// the intersection arithmetic.
+struct Walk {
+    int ix, iy, iz;
+    int stepx, stepy, stepz;
+    float tx, ty, tz;      // ray parameter at which the walk crosses the next x / y / z cell wall
+    float dtx, dty, dtz;   // parameter advance per cell
+    float t_enter;         // parameter at which the current cell was entered
+    bool alive;
+};
+
+__device__ __forceinline__ Walk walk_begin(const GridDesc& g, const Ray& ray, float t_limit) {
+    Walk w;
+    w.alive = false;
+    // the ray as a 3-D segment (the reference divides nothing by w here; start.w scales nothing in view space:
+    // secondary rays have w = 1, pinhole primaries too; other values are handled by the caller)
+    const float ox = ray.sx, oy = ray.sy, oz = ray.sz;
+    const float dx = ray.dx, dy = ray.dy, dz = ray.dz;
+    const float hix = g.lox + g.cell * (float)g.nx, hiy = g.loy + g.cell * (float)g.ny, hiz = g.loz + g.cell * (float)g.nz;
+    // slab clip against the grid box, [t0, t1] subset of [0, t_limit]
+    float t0 = 0.f, t1 = t_limit;
+    const float big = 3.0e38f;
+    {
+        const float inv = 1.0f / dx;
+        float a = (g.lox - ox) * inv, b = (hix - ox) * inv;
+        if (dx == 0.f) { a = (ox < g.lox || ox > hix) ? big : -big; b = (ox < g.lox || ox > hix) ? -big : big; }
+        t0 = __builtin_fmaxf(t0, __builtin_fminf(a, b));
+        t1 = __builtin_fminf(t1, __builtin_fmaxf(a, b));
+    }
+    {
+        const float inv = 1.0f / dy;
+        float a = (g.loy - oy) * inv, b = (hiy - oy) * inv;
+        if (dy == 0.f) { a = (oy < g.loy || oy > hiy) ? big : -big; b = (oy < g.loy || oy > hiy) ? -big : big; }
+        t0 = __builtin_fmaxf(t0, __builtin_fminf(a, b));
+        t1 = __builtin_fminf(t1, __builtin_fmaxf(a, b));
+    }
+    {
+        const float inv = 1.0f / dz;
+        float a = (g.loz - oz) * inv, b = (hiz - oz) * inv;
+        if (dz == 0.f) { a = (oz < g.loz || oz > hiz) ? big : -big; b = (oz < g.loz || oz > hiz) ? -big : big; }
+        t0 = __builtin_fmaxf(t0, __builtin_fminf(a, b));
+        t1 = __builtin_fminf(t1, __builtin_fmaxf(a, b));
+    }
+    if (!(t0 <= t1)) return w;  // misses the grid box (or NaN): only the always-list applies
+    const float px = ox + t0 * dx, py = oy + t0 * dy, pz = oz + t0 * dz;
+    int ix = (int)__builtin_floorf((px - g.lox) * g.inv_cell);
+    int iy = (int)__builtin_floorf((py - g.loy) * g.inv_cell);
+    int iz = (int)__builtin_floorf((pz - g.loz) * g.inv_cell);
+    ix = ix < 0 ? 0 : (ix >= g.nx ? g.nx - 1 : ix);
+    iy = iy < 0 ? 0 : (iy >= g.ny ? g.ny - 1 : iy);
+    iz = iz < 0 ? 0 : (iz >= g.nz ? g.nz - 1 : iz);
+    w.ix = ix; w.iy = iy; w.iz = iz;
+    w.stepx = dx > 0.f ? 1 : -1;
+    w.stepy = dy > 0.f ? 1 : -1;
+    w.stepz = dz > 0.f ? 1 : -1;
+    const float wallx = g.lox + g.cell * (float)(ix + (dx > 0.f ? 1 : 0));
+    const float wally = g.loy + g.cell * (float)(iy + (dy > 0.f ? 1 : 0));
+    const float wallz = g.loz + g.cell * (float)(iz + (dz > 0.f ? 1 : 0));
+    w.tx = dx != 0.f ? (wallx - ox) / dx : big;
+    w.ty = dy != 0.f ? (wally - oy) / dy : big;
+    w.tz = dz != 0.f ? (wallz - oz) / dz : big;
+    w.dtx = dx != 0.f ? g.cell / __builtin_fabsf(dx) : big;
+    w.dty = dy != 0.f ? g.cell / __builtin_fabsf(dy) : big;
+    w.dtz = dz != 0.f ? g.cell / __builtin_fabsf(dz) : big;
+    w.t_enter = t0;
+    w.alive = true;
+    return w;
+}
+
+// step to the next cell; false when the walk leaves the grid
+__device__ __forceinline__ bool walk_next(const GridDesc& g, Walk& w) {
+    if (w.tx <= w.ty && w.tx <= w.tz) {
+        w.ix += w.stepx; w.t_enter = w.tx; w.tx += w.dtx;
+        return (unsigned)w.ix < (unsigned)g.nx;
+    } else if (w.ty <= w.tz) {
+        w.iy += w.stepy; w.t_enter = w.ty; w.ty += w.dty;
+        return (unsigned)w.iy < (unsigned)g.ny;
+    } else {
+        w.iz += w.stepz; w.t_enter = w.tz; w.tz += w.dtz;
+        return (unsigned)w.iz < (unsigned)g.nz;
+    }
+}
+
+// Closest hit through the grid. Same (T, index) as closest_hit() over all objects.
+template <bool FUSED, bool DW0>
+__device__ __forceinline__ void closest_hit_grid(const GridDesc& g, const HotObject* __restrict__ hot, const Ray& ray, float& T,
+                                                 int& index, uint32_t& tested) {
+    bool cur_sphere = false;
+    tested = g.n_always;
+    for (uint32_t a = 0; a < g.n_always; ++a) {
+        const int k = (int)g.always[a];
+        float sx, sy, sz, dx, dy, dz;
+        uint32_t type;
+        lane_object_space<FUSED, DW0>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
+        closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, k, T, index, cur_sphere);
+    }
+    Walk w = walk_begin(g, ray, 3.0e38f);
+    if (!w.alive) return;
+    // two more cells after the best hit's cell (the candidate's own t is exact; the slack covers objects that
+    // start in the next cells but whose computed t the reference may place marginally earlier)
+    const float len = __builtin_sqrtf(ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz);
+    const float slack = len > 0.f ? 2.0f * g.cell / len : 3.0e38f;
+    for (;;) {
+        const uint32_t c = ((uint32_t)w.iz * (uint32_t)g.ny + (uint32_t)w.iy) * (uint32_t)g.nx + (uint32_t)w.ix;
+        const uint32_t e0 = g.cell_start[c], e1 = g.cell_start[c + 1];
+        tested += e1 - e0;
+        for (uint32_t e = e0; e < e1; ++e) {
+            const int k = (int)g.entries[e];
+            float sx, sy, sz, dx, dy, dz;
+            uint32_t type;
+            lane_object_space<FUSED, DW0>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
+            closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, k, T, index, cur_sphere);
+        }
+        if (!walk_next(g, w)) break;
+        if (w.t_enter > T + slack) break;  // T is +MAX until something is hit
+    }
+}
+
+// Any accepted candidate with t < 1 through the grid. Same answer as any_hit_before_one() over all objects.
+template <bool FUSED>
+__device__ __forceinline__ bool any_hit_grid(const GridDesc& g, const HotObject* __restrict__ hot, const Ray& ray,
+                                             uint32_t& tested) {
+    tested = 0;
+    for (uint32_t a = 0; a < g.n_always; ++a) {
+        ++tested;
+        const int k = (int)g.always[a];
+        float sx, sy, sz, dx, dy, dz;
+        uint32_t type;
+        lane_object_space<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
+        if (occludes<FUSED>(type, sx, sy, sz, dx, dy, dz)) return true;
+    }
+    // the segment up to the light, plus two cells of slack past t = 1
+    const float len = __builtin_sqrtf(ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz);
+    const float slack = len > 0.f ? 2.0f * g.cell / len : 3.0e38f;
+    Walk w = walk_begin(g, ray, 1.0f + slack);
+    if (!w.alive) return false;
+    for (;;) {
+        const uint32_t c = ((uint32_t)w.iz * (uint32_t)g.ny + (uint32_t)w.iy) * (uint32_t)g.nx + (uint32_t)w.ix;
+        const uint32_t e0 = g.cell_start[c], e1 = g.cell_start[c + 1];
+        for (uint32_t e = e0; e < e1; ++e) {
+            const int k = (int)g.entries[e];
+            float sx, sy, sz, dx, dy, dz;
+            uint32_t type;
+            ++tested;
+            lane_object_space<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
+            if (occludes<FUSED>(type, sx, sy, sz, dx, dy, dz)) return true;
+        }
+        if (!walk_next(g, w)) break;
+        if (w.t_enter > 1.0f + slack) break;
+    }
+    return false;
+}
+
+}  // namespace rt

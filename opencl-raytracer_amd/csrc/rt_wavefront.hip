@@ -15,6 +15,7 @@
 // is the same set of device functions as the monolithic kernel (rt_device.h), only the control flow is cut
 // at the traversal calls; tests require both paths to agree bit for bit.
 #include "rt_kernels.h"
+#include "rt_grid.h"
 
 #include <cstring>
 
@@ -43,6 +44,7 @@ struct WfParams {
     uint32_t* q_prev_any;
     uint32_t* counts;     // [0] closest next, [1] any next, [2] shadow-slice survivors (device counters)
     const HotPair* shadow_pairs;  // pair stream sorted by decreasing size, for order-free shadow tests
+    GridDesc grid;                // conservative uniform grid (enabled = 0: brute force)
     uint32_t n_prev_closest, n_prev_any;
     int kernel;
     uint32_t count_rays;  // instrumentation on
@@ -145,6 +147,34 @@ __global__ __launch_bounds__(256) void wf_trace_closest(const WfParams w, uint32
     const unsigned long long lanes = (unsigned long long)__popcll(__ballot(true));
     if (w.count_rays && (threadIdx.x & 63u) == 0u)  // 2 tests per pair for every ray of the wave
         atomicAdd(&w.rp.counters->tests, 2ull * w.rp.scene.n_pairs * lanes);
+}
+
+// The same two traversals through the conservative grid (rt_grid.h): identical results, a few hundred
+// candidate tests per ray instead of one per object.
+template <bool FUSED, bool DW0>
+__global__ __launch_bounds__(256) void wf_trace_closest_grid(const WfParams w, uint32_t n_queue) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_queue) return;
+    const uint64_t i = w.q_prev_closest[t];
+    const Ray ray = load_ray(w, i);
+    float T = kMaxFloat;
+    int idx = -1;
+    uint32_t tested = 0;
+    closest_hit_grid<FUSED, DW0>(w.grid, w.rp.scene.hot, ray, T, idx, tested);
+    F(w, F_RES_T, i) = T;
+    U(w, F_RES_I, i) = (uint32_t)idx;
+    if (w.count_rays) atomicAdd(&w.rp.counters->tests, (unsigned long long)tested);
+}
+
+template <bool FUSED>
+__global__ __launch_bounds__(256) void wf_trace_any_grid(const WfParams w, uint32_t n_queue) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_queue) return;
+    const uint64_t i = w.q_prev_any[t];
+    const Ray ray = load_ray(w, i);
+    uint32_t tested = 0;
+    U(w, F_RES_I, i) = any_hit_grid<FUSED>(w.grid, w.rp.scene.hot, ray, tested) ? 0u : 1u;
+    if (w.count_rays) atomicAdd(&w.rp.counters->tests, (unsigned long long)tested);
 }
 
 // Literal shadow test: the reference's full closest hit, then its `time >= 1 || time < 0` (:229).
@@ -445,6 +475,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
     w.st = buf.state;
     w.counts = buf.counts;
     w.shadow_pairs = buf.shadow_pairs;
+    w.grid = buf.grid;
     w.q_closest = q[cur][0];
     w.q_any = q[cur][1];
     hipLaunchKernelGGL(wf_begin, grid_for(n), dim3(256), 0, stream, w);
@@ -463,14 +494,23 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
         w.q_prev_any = q[cur][1];
         w.n_prev_closest = nc;
         w.n_prev_any = na;
+        const bool use_grid = w.grid.enabled && !w.rp.scene.literal;
         if (nc) {
-            if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
-            else hipLaunchKernelGGL((wf_trace_closest<FUSED, true>), grid_for(nc), dim3(256), 0, stream, w, nc);
+            if (use_grid) {
+                if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest_grid<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
+                else hipLaunchKernelGGL((wf_trace_closest_grid<FUSED, true>), grid_for(nc), dim3(256), 0, stream, w, nc);
+            } else {
+                if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
+                else hipLaunchKernelGGL((wf_trace_closest<FUSED, true>), grid_for(nc), dim3(256), 0, stream, w, nc);
+            }
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (na) {
             if (w.rp.scene.literal) {
                 hipLaunchKernelGGL((wf_trace_any_literal<FUSED>), grid_for(na), dim3(256), 0, stream, w, na);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            } else if (use_grid) {
+                hipLaunchKernelGGL((wf_trace_any_grid<FUSED>), grid_for(na), dim3(256), 0, stream, w, na);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             } else {
                 // slices of >= kMinSlicePairs pairs (amortises each launch's pipeline fill), at most kMaxSlices

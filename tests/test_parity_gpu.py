@@ -29,9 +29,11 @@ def hip(*a, **k):
 def test_golden_vectors(name, fused):
     fx = load_fixture(name)
     want = expected_full(fx, fused)
-    for literal, path in ((False, "monolithic"), (True, "monolithic"), (False, "wavefront"), (True, "wavefront")):
+    # monolithic / wavefront with the conservative grid / wavefront brute force / literal (every reference ray)
+    for literal, path, grid in ((False, "monolithic", True), (True, "monolithic", True), (False, "wavefront", True),
+                                (False, "wavefront", False), (True, "wavefront", True)):
         with hip(fx["objs"], fx["lights"], fx["rays"], fx["max_bounces"], kernel=fx["kernel"], fused=fused,
-                 literal=literal, path=path) as rt:
+                 literal=literal, path=path, grid=grid) as rt:
             got = rt.Render()
             assert rt.stats().wavefront == int(path == "wavefront")
         if fx["kernel"] == 0:
@@ -63,10 +65,13 @@ def test_random_scenes_vs_oracle(seed, n_s, n_b, n_l, res, fused, restatement):
     for kernel in ("hittest", "shade", "shade_and_reflect"):
         want = restatement[fused].render(kernel, objs, lights, rays, 3)
         outs = {}
-        for literal, raygen, path in ((False, True, "monolithic"), (False, False, "monolithic"), (True, True, "monolithic"),
-                                      (True, False, "monolithic"), (False, True, "wavefront"), (True, False, "wavefront")):
+        for literal, raygen, path, grid in ((False, True, "monolithic", True), (False, False, "monolithic", True),
+                                            (True, True, "monolithic", True), (True, False, "monolithic", True),
+                                            (False, True, "wavefront", True), (False, False, "wavefront", False),
+                                            (True, False, "wavefront", True)):
             if True:
-                with hip(objs, lights, rays, 3, kernel=kernel, fused=fused, literal=literal, raygen=raygen, path=path) as rt:
+                with hip(objs, lights, rays, 3, kernel=kernel, fused=fused, literal=literal, raygen=raygen, path=path,
+                         grid=grid) as rt:
                     out = rt.Render()
                     t, idx = rt.render_aux()
                     st = rt.count_rays()
@@ -82,9 +87,9 @@ def test_random_scenes_vs_oracle(seed, n_s, n_b, n_l, res, fused, restatement):
                     assert same_floats(out, want["out"])
                 else:
                     assert compare_frames(out, want["out"]) <= RGB_ATOL
-                outs[(literal, raygen, path)] = out
+                outs[(literal, raygen, path, grid)] = out
         # the exact eliminations, in-kernel ray generation and the wavefront path must not change a single bit
-        base = outs[(True, False, "monolithic")]
+        base = outs[(True, False, "monolithic", True)]
         for key, o in outs.items():
             assert np.array_equal(o.view(np.uint32), base.view(np.uint32)), f"{kernel} {key} differs from literal"
 
@@ -227,16 +232,16 @@ def test_large_scene_sliced_shadow_stream_vs_oracle(restatement):
     want = restatement[True].render("shade_and_reflect", objs, lights, rays, 2)
     assert int((want["hit_index"] >= 0).sum()) > 500
     outs = {}
-    for path, literal in (("auto", False), ("auto", True), ("monolithic", False)):
-        with hip(objs, lights, rays, 2, path=path, literal=literal) as rt:
-            outs[(path, literal)] = rt.Render()
+    for path, literal, grid in (("auto", False, True), ("auto", False, False), ("auto", True, True), ("monolithic", False, True)):
+        with hip(objs, lights, rays, 2, path=path, literal=literal, grid=grid) as rt:
+            outs[(path, literal, grid)] = rt.Render()
             t, idx = rt.render_aux()
             st = rt.count_rays()
         assert st.wavefront == int(path == "auto")
         assert np.array_equal(idx, want["hit_index"]) and same_floats(t, want["hit_t"])
         assert st.rays_reference == want["rays_ref"]
-        assert compare_frames(outs[(path, literal)], want["out"]) <= RGB_ATOL
-    base = outs[("monolithic", False)]
+        assert compare_frames(outs[(path, literal, grid)], want["out"]) <= RGB_ATOL
+    base = outs[("monolithic", False, True)]
     for o in outs.values():
         assert np.array_equal(o.view(np.uint32), base.view(np.uint32))
     # the shade kernel (every light's shadow ray, summed) through the same machinery
@@ -259,8 +264,14 @@ def test_config4_scene_window_properties(restatement):
         a = rt.Render()
         b = rt.Render()
         st = rt.count_rays()
-    assert st.wavefront == 1 and st.object_tests > 0
+    assert st.wavefront == 1
     assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # brute force over all 100 000 objects (no grid culling): the same bits, and it counts its ray-object tests
+    with hip(objs, lights, big, 3, grid=False) as rt:
+        brute = rt.Render()
+        stb = rt.count_rays()
+    assert np.array_equal(brute.view(np.uint32), a.view(np.uint32))
+    assert stb.object_tests > 100_000 * 128 * 128 and stb.rays_reference == st.rays_reference and stb.rays_traced == st.rays_traced
     a = a.reshape(128, 128, 4)
     # the inner 32x32 window rendered on its own: same pixels, bit for bit
     small = camera.crop_rays(W, H, 2048 - 16, 2048 - 16, 32, 32)
