@@ -86,17 +86,49 @@ __device__ __forceinline__ void push(uint32_t* queue, uint32_t* counter, uint64_
     queue[slot] = (uint32_t)i;
 }
 
+// Queue appends of a whole workgroup with ONE atomic per queue: a single global counter takes ~88 returning
+// atomics per microsecond on this chip, so one per wave (262 144 waves per round at 4096^2) would cost 3 ms a
+// round. Order inside the workgroup is preserved (neighbouring pixels stay neighbours in the next trace).
+constexpr int kResumeThreads = 1024;
+__device__ __forceinline__ void block_push(bool want_closest, bool want_any, uint32_t id, uint32_t* __restrict__ q_closest,
+                                           uint32_t* __restrict__ q_any, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t s_cnt[2][kResumeThreads / 64];
+    __shared__ uint32_t s_base[2];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t n_waves = (blockDim.x + 63u) >> 6;
+    const unsigned long long bc = __ballot(want_closest), ba = __ballot(want_any);
+    if (lane == 0u) { s_cnt[0][wave] = (uint32_t)__popcll(bc); s_cnt[1][wave] = (uint32_t)__popcll(ba); }
+    __syncthreads();
+    if (threadIdx.x < 2u) {
+        uint32_t total = 0;
+        for (uint32_t k = 0; k < n_waves; ++k) { const uint32_t c = s_cnt[threadIdx.x][k]; s_cnt[threadIdx.x][k] = total; total += c; }
+        s_base[threadIdx.x] = total ? atomicAdd(&counts[threadIdx.x], total) : 0u;
+    }
+    __syncthreads();
+    const unsigned long long below = (1ull << lane) - 1ull;
+    if (want_closest) q_closest[s_base[0] + s_cnt[0][wave] + (uint32_t)__popcll(bc & below)] = id;
+    if (want_any) q_any[s_base[1] + s_cnt[1][wave] + (uint32_t)__popcll(ba & below)] = id;
+}
+
 __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
+__device__ __forceinline__ bool begin_pixel(const WfParams& w, uint64_t i);
+
 // ---- wf_begin: primary rays --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wf_begin(const WfParams w) {
+__global__ __launch_bounds__(kResumeThreads) void wf_begin(const WfParams w) {
     const RenderParams& p = w.rp;
-    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    if (i >= p.n_local) return;
+    const uint64_t i = (uint64_t)blockIdx.x * kResumeThreads + threadIdx.x;
+    bool want = false;
+    if (i < p.n_local) want = begin_pixel(w, i);
+    block_push(want, false, (uint32_t)i, w.q_closest, w.q_any, w.counts);
+}
+
+__device__ __forceinline__ bool begin_pixel(const WfParams& w, uint64_t i) {
+    const RenderParams& p = w.rp;
     uint64_t g = i;
     if (p.world > 1u) {
         const uint64_t tile = i / p.tile_rays;
@@ -109,7 +141,7 @@ __global__ __launch_bounds__(256) void wf_begin(const WfParams w) {
         if (p.aux_t) p.aux_t[i] = kMaxFloat;
         if (p.aux_index) p.aux_index[i] = -1;
         U(w, F_PHASE, i) = PH_DONE;
-        return;
+        return false;
     }
     Ray ray;
     if (p.pinhole) {
@@ -129,7 +161,7 @@ __global__ __launch_bounds__(256) void wf_begin(const WfParams w) {
     }
     store_ray(w, i, ray);
     U(w, F_PHASE, i) = PH_PRIMARY;
-    push(w.q_closest, &w.counts[0], i);
+    return true;
 }
 
 // ---- lean traversal kernels ----------------------------------------------------------------------------------------
@@ -227,6 +259,7 @@ struct Ctx {
     const WfParams& w;
     uint64_t i;
     unsigned long long traced, reference, hits;
+    bool want_closest, want_any;  // the pixel queued a ray for the next round (appended by block_push at the end)
 };
 
 template <int KERNEL>
@@ -248,7 +281,7 @@ __device__ __forceinline__ void emit_shadow(Ctx& c, const HitRec& h, uint32_t li
     store_ray(c.w, c.i, g.shadow);
     U(c.w, F_LI, c.i) = li;
     U(c.w, F_PHASE, c.i) = phase;
-    push(c.w.q_any, &c.w.counts[1], c.i);
+    c.want_any = true;
     c.traced += 1;
 }
 
@@ -374,7 +407,7 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
     F(c.w, F_AP, i) = ap;
     U(c.w, F_BOUNCES, i) = bounces;
     U(c.w, F_PHASE, i) = PH_REFLECT;
-    push(c.w.q_closest, &c.w.counts[0], i);
+    c.want_closest = true;
     c.traced += 1;
 }
 
@@ -398,10 +431,10 @@ __device__ void shade_done(Ctx& c, const HitRec& h, bool primary, float cr, floa
 }
 
 template <int KERNEL, bool FUSED>
-__global__ __launch_bounds__(256) void wf_resume(const WfParams w) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+__global__ __launch_bounds__(kResumeThreads) void wf_resume(const WfParams w) {
+    const uint32_t t = blockIdx.x * kResumeThreads + threadIdx.x;
     const uint32_t total = w.n_prev_closest + w.n_prev_any;
-    Ctx c{w, 0, 0ull, 0ull, 0ull};
+    Ctx c{w, 0, 0ull, 0ull, 0ull, false, false};
     if (t < total) {
         const uint64_t i = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
         c.i = i;
@@ -446,6 +479,7 @@ __global__ __launch_bounds__(256) void wf_resume(const WfParams w) {
             }
         }
     }
+    block_push(c.want_closest, c.want_any, (uint32_t)c.i, w.q_closest, w.q_any, w.counts);
     if (w.count_rays) {
         const unsigned long long a = wave_sum64(c.traced), b = wave_sum64(c.reference), h = wave_sum64(c.hits);
         if ((threadIdx.x & 63u) == 0u && (a | b | h)) {
@@ -478,7 +512,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
     w.grid = buf.grid;
     w.q_closest = q[cur][0];
     w.q_any = q[cur][1];
-    hipLaunchKernelGGL(wf_begin, grid_for(n), dim3(256), 0, stream, w);
+    hipLaunchKernelGGL(wf_begin, dim3((uint32_t)((n + kResumeThreads - 1) / kResumeThreads)), dim3(kResumeThreads), 0, stream, w);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     uint32_t rounds = 0;
     bool first = true;
@@ -541,7 +575,8 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
         w.q_closest = q[cur][0];
         w.q_any = q[cur][1];
         if ((e = hipMemsetAsync(buf.counts, 0, 2 * sizeof(uint32_t), stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL((wf_resume<KERNEL, FUSED>), grid_for((uint64_t)nc + na), dim3(256), 0, stream, w);
+        hipLaunchKernelGGL((wf_resume<KERNEL, FUSED>), dim3((uint32_t)(((uint64_t)nc + na + kResumeThreads - 1) / kResumeThreads)),
+                           dim3(kResumeThreads), 0, stream, w);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (rounds_out) *rounds_out = rounds;
