@@ -73,6 +73,45 @@ inline mat4 scale(const mat4& m, const vec3& v) {
     return r;
 }
 
+inline vec3 normalize(const vec3& v) {
+    const float inv = 1.0f / std::sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+    return vec3(v.x * inv, v.y * inv, v.z * inv);
+}
+inline vec3 cross(const vec3& a, const vec3& b) { return vec3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+inline float dot(const vec3& a, const vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float radians(float deg) { return deg * 0.01745329251994329576923690768489f; }
+
+// axis-angle rotation appended to m (axis must be normalised), glm's formulation
+inline mat4 rotate(const mat4& m, float angle, const vec3& axis) {
+    const float c = std::cos(angle), s = std::sin(angle);
+    const vec3 t((1.f - c) * axis.x, (1.f - c) * axis.y, (1.f - c) * axis.z);
+    float r[3][3];
+    r[0][0] = c + t.x * axis.x;          r[0][1] = t.x * axis.y + s * axis.z; r[0][2] = t.x * axis.z - s * axis.y;
+    r[1][0] = t.y * axis.x - s * axis.z; r[1][1] = c + t.y * axis.y;          r[1][2] = t.y * axis.z + s * axis.x;
+    r[2][0] = t.z * axis.x + s * axis.y; r[2][1] = t.z * axis.y - s * axis.x; r[2][2] = c + t.z * axis.z;
+    mat4 out(0.f);
+    for (int i = 0; i < 4; ++i) {
+        out.c[0][i] = m.c[0][i] * r[0][0] + m.c[1][i] * r[0][1] + m.c[2][i] * r[0][2];
+        out.c[1][i] = m.c[0][i] * r[1][0] + m.c[1][i] * r[1][1] + m.c[2][i] * r[1][2];
+        out.c[2][i] = m.c[0][i] * r[2][0] + m.c[1][i] * r[2][1] + m.c[2][i] * r[2][2];
+        out.c[3][i] = m.c[3][i];
+    }
+    return out;
+}
+
+// right-handed look-at
+inline mat4 lookAt(const vec3& eye, const vec3& center, const vec3& up) {
+    const vec3 f = normalize(vec3(center.x - eye.x, center.y - eye.y, center.z - eye.z));
+    const vec3 s = normalize(cross(f, up));
+    const vec3 u = cross(s, f);
+    mat4 r(1.f);
+    r.c[0][0] = s.x; r.c[1][0] = s.y; r.c[2][0] = s.z;
+    r.c[0][1] = u.x; r.c[1][1] = u.y; r.c[2][1] = u.z;
+    r.c[0][2] = -f.x; r.c[1][2] = -f.y; r.c[2][2] = -f.z;
+    r.c[3][0] = -dot(s, eye); r.c[3][1] = -dot(u, eye); r.c[3][2] = dot(f, eye);
+    return r;
+}
+
 inline mat4 transpose(const mat4& m) {
     mat4 r(0.f);
     for (int i = 0; i < 4; ++i)

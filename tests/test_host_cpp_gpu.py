@@ -30,3 +30,21 @@ def test_cpp_host_renders_config1(tmp_path):
     want = expected_full(fx, fused=True)
     assert compare_frames(frame, want) <= 1e-5
     assert np.array_equal(np.any(frame[:, :3] != 0, axis=1), np.any(want[:, :3] != 0, axis=1))
+
+
+def test_cpp_scene_tool_config1_ppm_known_answer(tmp_path):
+    """SceneLoader -> rays -> HIPRaytracer -> PPMExporter in C++, end to end on BASELINE config 1: the P3 file is
+    byte-identical to the one the reference's kernels + PPMExporter produce (397 825 bytes, md5 28365bd1...)."""
+    import hashlib
+    tool = ROOT / "opencl-raytracer_amd" / "host" / "scene_tool"
+    if not tool.exists():
+        import __graft_entry__
+        __graft_entry__.build()
+    out = tmp_path / "render.ppm"
+    zbits = np.float32(camera.camera_z(256)).view(np.uint32)
+    res = subprocess.run([str(tool), "render", str(ROOT / "scenes" / "simpleSphere.txt"), "256", "256", "3", str(out), f"{int(zbits):08x}"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    blob = out.read_bytes()
+    assert len(blob) == 397825
+    assert hashlib.md5(blob).hexdigest() == "28365bd12a502710be0c9a9a1a8057a9"

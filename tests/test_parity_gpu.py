@@ -291,3 +291,59 @@ def test_config4_scene_window_properties(restatement):
             rt.set_shard(128 * 16, rank, 2)
             pieces.append(rt.Render())
     assert np.array_equal(assemble_frame(pieces, 128 * 16, 128 * 128).view(np.uint32), a.reshape(-1, 4).view(np.uint32))
+
+
+def _grid_equals_brute(objs, lights, rays, depth, kernels=("shade_and_reflect",)):
+    for kernel in kernels:
+        with hip(objs, lights, rays, depth, kernel=kernel, path="wavefront", grid=True) as rt:
+            a = rt.Render()
+            ta, ia = rt.render_aux()
+            sa = rt.count_rays()
+        with hip(objs, lights, rays, depth, kernel=kernel, path="wavefront", grid=False) as rt:
+            b = rt.Render()
+            tb, ib = rt.render_aux()
+            sb = rt.count_rays()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), f"{kernel}: grid and brute-force frames differ"
+        assert np.array_equal(ia, ib) and same_floats(ta, tb)
+        assert sa.rays_reference == sb.rays_reference and sa.rays_traced == sb.rays_traced
+    return a
+
+
+def test_grid_mixed_boxes_and_spheres(restatement):
+    """2 000 rotated, non-uniformly scaled boxes and spheres, positional + directional lights, reflective materials:
+    grid == brute force bit for bit, and both match the oracle."""
+    objs, lights = random_scene(1200, 800, 4, seed=909, directional_lights=1, spread=14.0, zrange=(-60.0, -12.0))
+    rays = camera.primary_rays(96, 64)
+    got = _grid_equals_brute(objs, lights, rays, 3, kernels=("hittest", "shade", "shade_and_reflect"))
+    want = restatement[True].render("shade_and_reflect", objs, lights, rays, 3)
+    assert compare_frames(got, want["out"]) <= RGB_ATOL
+    assert int((want["hit_index"] >= 0).sum()) > 3000
+
+
+def test_grid_tiny_far_objects_numerical_fuzz():
+    """Radius-0.01 spheres 60-140 units away: |o| ~ 1e4 object units, where the reference's own discriminant
+    accepts rays that miss the sphere by many radii. The grid margins must keep every such false hit."""
+    rng = np.random.default_rng(4242)
+    n = 3000
+    from helpers import instance
+    recs = []
+    for i in range(n):
+        pos = (rng.uniform(-40, 40), rng.uniform(-40, 40), rng.uniform(-140, -60))
+        r = rng.choice([0.01, 0.02, 0.05])
+        mv, inv = instance(pos, None, (r, r, r))
+        recs.append(R.make_object(R.SPHERE, R.Material((rng.uniform(), rng.uniform(), rng.uniform()), (.5, .5, .5), (.5, .5, .5),
+                                                       absorption=0.5), mv, inv))
+    objs = R.objects_array(recs)
+    lights = R.lights_array([R.make_light(R.LightProperties((.3, .3, .3), (.7, .7, .7), (1, 1, 1)), position=(10, 10, 0, 1)),
+                             R.make_light(R.LightProperties((.1, .1, .1), (.4, .4, .4), (.5, .5, .5)), position=(-30, 5, -100, 1))])
+    # aim a dense bundle of rays at the cloud so that plenty of them graze spheres
+    rays = camera.crop_rays(4096, 4096, 1536, 1536, 256, 256)
+    out = _grid_equals_brute(objs, lights, rays, 2)
+    assert int(np.any(out[:, :3] != 0, axis=1).sum()) > 50
+
+
+def test_grid_rays_starting_inside_objects_and_lights_inside_the_cloud():
+    objs, lights = random_scene(700, 300, 3, seed=1234, spread=5.0, zrange=(-14.0, 4.0))  # the camera sits inside the cloud
+    lights["position"][0] = (0.5, -0.5, -6.0, 1.0)                                          # a light in the middle of it
+    rays = camera.primary_rays(80, 60)
+    _grid_equals_brute(objs, lights, rays, 4, kernels=("shade", "shade_and_reflect"))
