@@ -207,7 +207,7 @@ __device__ __forceinline__ bool box_candidate(float sx, float sy, float sz, floa
 // aligned SGPR pair. One v_pk_fma_f32 / v_pk_mul_f32 then does the same multiply-add for BOTH objects:
 // measured on gfx950 a VALU instruction with an SGPR source issues at ~4.4 cycles per wave against ~2.3 for an
 // all-VGPR one, while the packed form with the same SGPR source also costs ~4.3 cycles but retires two
-// objects (scratch/ubench/valu2.hip). Each packed lane is an ordinary IEEE fp32 mul / fma, so every bit of
+// objects (tools/ubench/valu_issue_rate.hip). Each packed lane is an ordinary IEEE fp32 mul / fma, so every bit of
 // s_obj, d_obj and the discriminant is identical to the one-object-at-a-time evaluation.
 //
 // The packed part is only a FILTER: it computes the reference's `radical` for both spheres of a pair; lanes

@@ -347,3 +347,21 @@ def test_grid_rays_starting_inside_objects_and_lights_inside_the_cloud():
     lights["position"][0] = (0.5, -0.5, -6.0, 1.0)                                          # a light in the middle of it
     rays = camera.primary_rays(80, 60)
     _grid_equals_brute(objs, lights, rays, 4, kernels=("shade", "shade_and_reflect"))
+
+
+def test_device_resident_render_through_torch_plumbing():
+    """rt_render_device into a torch tensor on torch's current stream (what bench.py and the multi-GPU path use)
+    gives the same bytes as the host-buffer Render()."""
+    import torch
+    from opencl_raytracer_amd.distributed import ShardedHIPRaytracer
+    objs, lights = random_scene(10, 6, 2, seed=66)
+    W, H = 128, 80
+    z = float(camera.camera_z(H))
+    with hip(objs, lights, None, 3, camera=(W, H, z)) as rt:
+        want = rt.Render()
+    srt = ShardedHIPRaytracer(objs, lights, None, 3, camera=(W, H, z), tile_rows=16)
+    frame = srt.Render()
+    torch.cuda.synchronize()
+    got = frame.cpu().numpy()
+    srt.close()
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
