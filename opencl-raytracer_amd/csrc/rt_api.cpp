@@ -42,8 +42,7 @@ struct rt_context {
     float4* d_bounds = nullptr;            // screen rectangles for the current camera
     std::vector<double> h_spheres;         // per object: bounding sphere cx, cy, cz, R (R = +inf never cull, -inf never hit)
     bool rects_dirty = true;
-    uint32_t* d_work_counter = nullptr;    // bundle dispenser of the persistent kernel
-    uint32_t work_counter_value = 0;       // what the device counter holds once all queued launches have run
+
     rt::LightRec* d_lights = nullptr;
     float4* d_rays = nullptr;
     bool have_rays = false;  // ray buffer uploaded
@@ -433,8 +432,6 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
         RT_HIP(c, hipStreamSynchronize(stream));  // `rects` is pageable host memory
         c->rects_dirty = false;
     }
-    p.work_counter = c->d_work_counter;
-    p.work_base = c->work_counter_value;
     if (count) RT_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters), stream));
     const uint32_t slot = c->ev_count % kTimingSlots;
     RT_HIP(c, hipEventRecord(c->ev_begin[slot], stream));
@@ -446,9 +443,7 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
         if (rc) return rc;
         e = rt::launch_wavefront(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, c->wf, stream, &c->last_rounds);
     } else {
-        uint32_t waves = 0;
-        e = rt::launch_render(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, stream, &waves);
-        c->work_counter_value += p.n_bundles + waves;  // where the device counter stands after this launch
+        e = rt::launch_render(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, stream);
     }
     if (e != hipSuccess) return fail_hip(c, e, "kernel launch");
     RT_HIP(c, hipEventRecord(c->ev_end[slot], stream));
@@ -671,8 +666,6 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
             }
         }
         RT_TRY(hipMalloc((void**)&c->d_bounds, sizeof(float4) * 65));
-        RT_TRY(hipMalloc((void**)&c->d_work_counter, sizeof(uint32_t)));
-        RT_TRY(hipMemset(c->d_work_counter, 0, sizeof(uint32_t)));
         if (n_objs) {
             RT_TRY(hipMemcpy(c->d_hot, hot.data(), sizeof(rt::HotObject) * n_objs, hipMemcpyHostToDevice));
             RT_TRY(hipMemcpy(c->d_cold, cold.data(), sizeof(rt::ColdObject) * n_objs, hipMemcpyHostToDevice));
@@ -865,7 +858,6 @@ void rt_destroy(rt_context* c) {
     if (c->d_hot) (void)hipFree(c->d_hot);
     if (c->d_cold) (void)hipFree(c->d_cold);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
-    if (c->d_work_counter) (void)hipFree(c->d_work_counter);
     if (c->d_grid_cell_start) (void)hipFree(c->d_grid_cell_start);
     if (c->d_grid_entries) (void)hipFree(c->d_grid_entries);
     if (c->d_grid_always) (void)hipFree(c->d_grid_always);

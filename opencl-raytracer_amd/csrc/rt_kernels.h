@@ -23,8 +23,6 @@ struct RenderParams {
     uint32_t local_rows;              // rows this rank renders
     uint32_t tile_rows;               // rows per shard tile
     uint32_t n_bundles;               // 8x8 bundles (tile2d) or 64-ray chunks of this launch
-    uint32_t* work_counter;           // monotonically increasing device counter the waves draw bundles from
-    uint32_t work_base;               // its value at the start of this launch
     uint32_t max_bounces;
     void* out;                        // float4 per work-item (kernels 1,2) or float (kernel 0)
     float* aux_t;                     // optional
@@ -32,10 +30,7 @@ struct RenderParams {
     Counters* counters;               // used by counted launches only
 };
 
-// waves_launched: every wave draws exactly one out-of-range ticket from work_counter before it exits, so the
-// counter ends at work_base + n_bundles + waves_launched (the host tracks it instead of resetting it).
-hipError_t launch_render(const RenderParams& p, int kernel, bool fused, bool count, hipStream_t stream,
-                         uint32_t* waves_launched);
+hipError_t launch_render(const RenderParams& p, int kernel, bool fused, bool count, hipStream_t stream);
 
 // large-N path (rt_wavefront.hip): traversal and shading as separate kernels, pixel state in HBM
 struct WavefrontBuffers {

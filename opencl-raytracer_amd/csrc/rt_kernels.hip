@@ -153,24 +153,8 @@ __global__ __launch_bounds__(256) void render_pixels(const RenderParams p) {
     }
 }
 
-// resident workgroups of one kernel on the current device (cached per instantiation)
-template <typename K>
-static uint32_t resident_blocks(K kernel) {
-    static uint32_t cached = 0;
-    if (cached) return cached;
-    int dev = 0, cus = 256, per_cu = 4;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    }
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-    cached = (uint32_t)cus * (uint32_t)per_cu;
-    return cached;
-}
-
 template <int KERNEL, bool FUSED>
-static hipError_t launch2(const RenderParams& p, bool count, hipStream_t stream, uint32_t* waves_launched) {
-    *waves_launched = 0;
+static hipError_t launch2(const RenderParams& p, bool count, hipStream_t stream) {
     if (p.n_bundles == 0) return hipSuccess;
     uint32_t blocks;
     if (p.tile2d) blocks = ((p.bundles_x + 1u) / 2u) * ((((p.local_rows + 7u) / 8u) + 1u) / 2u);  // 2x2 bundles each
@@ -181,12 +165,11 @@ static hipError_t launch2(const RenderParams& p, bool count, hipStream_t stream,
     return hipGetLastError();
 }
 
-hipError_t launch_render(const RenderParams& p, int kernel, bool fused, bool count, hipStream_t stream,
-                         uint32_t* waves_launched) {
+hipError_t launch_render(const RenderParams& p, int kernel, bool fused, bool count, hipStream_t stream) {
     switch (kernel) {
-        case 0: return fused ? launch2<0, true>(p, count, stream, waves_launched) : launch2<0, false>(p, count, stream, waves_launched);
-        case 1: return fused ? launch2<1, true>(p, count, stream, waves_launched) : launch2<1, false>(p, count, stream, waves_launched);
-        case 2: return fused ? launch2<2, true>(p, count, stream, waves_launched) : launch2<2, false>(p, count, stream, waves_launched);
+        case 0: return fused ? launch2<0, true>(p, count, stream) : launch2<0, false>(p, count, stream);
+        case 1: return fused ? launch2<1, true>(p, count, stream) : launch2<1, false>(p, count, stream);
+        case 2: return fused ? launch2<2, true>(p, count, stream) : launch2<2, false>(p, count, stream);
         default: return hipErrorInvalidValue;
     }
 }
