@@ -68,6 +68,11 @@ struct rt_context {
     uint32_t* d_grid_cell_start = nullptr;
     uint32_t* d_grid_entries = nullptr;
     uint32_t* d_grid_always = nullptr;
+    std::vector<double> h_grid_spheres;     // per object: centre + grid radius (inf: always tested, < 0: never hit)
+    uint32_t* d_tile_start = nullptr;       // screen tiles (64 x 8 pixels) -> objects a pinhole primary ray can reach
+    uint32_t* d_tile_entries = nullptr;
+    rt::ScreenTiles tiles = {};
+    bool tiles_dirty = true;
     bool affine_w = true;                   // every mv / mvInverse has bottom row (0,0,0,1) exactly
     bool primary_w_one = true;              // every uploaded primary ray has start.w == 1
     double origin_lo[3] = {0, 0, 0}, origin_hi[3] = {0, 0, 0};  // box of the primary ray origins
@@ -369,6 +374,8 @@ int ensure_wavefront(rt_context* c) {
     return RT_OK;
 }
 
+int build_screen_tiles(rt_context* c, hipStream_t stream);
+
 int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     if (c->n_local == 0) {  // empty launch: nothing to render, nothing to time
         if (count) c->counters = rt::Counters{0, 0, 0, 0};
@@ -439,8 +446,13 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     c->last_wavefront = use_wavefront(c);
     c->last_rounds = 0;
     if (c->last_wavefront) {
-        const int rc = ensure_wavefront(c);
+        int rc = ensure_wavefront(c);
         if (rc) return rc;
+        if (c->tiles_dirty) {
+            rc = build_screen_tiles(c, stream);
+            if (rc) return rc;
+        }
+        c->wf.tiles = c->tiles;
         e = rt::launch_wavefront(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, c->wf, stream, &c->last_rounds);
     } else {
         e = rt::launch_render(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, stream);
@@ -451,6 +463,65 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     // aux buffers apply to one render only
     c->aux_t = nullptr;
     c->aux_index = nullptr;
+    return RT_OK;
+}
+
+// Primary rays of a pinhole grid: per screen tile (64 x 8 pixels) the objects whose conservative screen rectangle
+// (projection of the grid sphere, i.e. with the same error-bound inflation) overlaps the tile, ascending index.
+// A wave of the first trace round holds 64 consecutive pixels of one row = one tile, so it walks that list with
+// wave-uniform scalar loads instead of 64 separate grid walks.
+int build_screen_tiles(rt_context* c, hipStream_t stream) {
+    c->tiles = rt::ScreenTiles{};
+    c->tiles_dirty = false;
+    if (!c->grid.enabled || !c->pinhole || !(c->z < 0.f) || c->width % 64u != 0 || c->h_grid_spheres.empty()) return RT_OK;
+    const uint32_t tx = c->width / 64u, ty = (c->height + 7u) / 8u;
+    const size_t n_tiles = (size_t)tx * ty;
+    const uint32_t n = c->n_objs;
+    const double half_w = (double)((float)c->width / 2.0f), half_h = (double)((float)c->height / 2.0f), H = (double)c->height;
+    const double inf = std::numeric_limits<double>::infinity();
+    std::vector<uint32_t> start(n_tiles + 1, 0), entries, fill;
+    struct Range { int x0, x1, y0, y1; };
+    std::vector<Range> rng(n);
+    size_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const double r = c->h_grid_spheres[4 * i + 3];
+        Range& q = rng[i];
+        q.x0 = 0; q.x1 = -1; q.y0 = 0; q.y1 = -1;
+        if (!(r >= 0) || r == inf) continue;  // never hit / always-list (handled by the kernel)
+        const float4 rect = screen_rect(Sphere{c->h_grid_spheres[4 * i], c->h_grid_spheres[4 * i + 1], c->h_grid_spheres[4 * i + 2], r}, (double)c->z);
+        if (!(rect.x <= rect.y) || !(rect.z <= rect.w)) continue;  // empty: behind the camera
+        // direction x = col - W/2  ->  col range; direction y = (H - row) - H/2  ->  row range
+        const double c0 = (double)rect.x + half_w, c1 = (double)rect.y + half_w;
+        const double r0 = H - half_h - (double)rect.w, r1 = H - half_h - (double)rect.z;
+        const double cx0 = std::max(0.0, std::floor(c0)), cx1 = std::min((double)c->width - 1, std::ceil(c1));
+        const double ry0 = std::max(0.0, std::floor(r0)), ry1 = std::min((double)c->height - 1, std::ceil(r1));
+        if (cx0 > cx1 || ry0 > ry1) continue;
+        q.x0 = (int)(cx0 / 64); q.x1 = (int)(cx1 / 64); q.y0 = (int)(ry0 / 8); q.y1 = (int)(ry1 / 8);
+        for (int y = q.y0; y <= q.y1; ++y)
+            for (int x = q.x0; x <= q.x1; ++x) start[(size_t)y * tx + x + 1] += 1;
+    }
+    for (size_t k = 0; k < n_tiles; ++k) start[k + 1] += start[k];
+    total = start[n_tiles];
+    if (total > 256ull * n + 4096) return RT_OK;  // objects cover most of the screen: the grid walk is the better tool
+    entries.assign(total, 0);
+    fill.assign(start.begin(), start.end() - 1);
+    for (uint32_t i = 0; i < n; ++i) {
+        const Range& q = rng[i];
+        for (int y = q.y0; y <= q.y1; ++y)
+            for (int x = q.x0; x <= q.x1; ++x) entries[fill[(size_t)y * tx + x]++] = i;
+    }
+    if (c->d_tile_start) (void)hipFree(c->d_tile_start);
+    if (c->d_tile_entries) (void)hipFree(c->d_tile_entries);
+    c->d_tile_start = c->d_tile_entries = nullptr;
+    RT_HIP(c, hipMalloc((void**)&c->d_tile_start, sizeof(uint32_t) * (n_tiles + 1)));
+    RT_HIP(c, hipMalloc((void**)&c->d_tile_entries, sizeof(uint32_t) * (total + 1)));
+    RT_HIP(c, hipMemcpyAsync(c->d_tile_start, start.data(), sizeof(uint32_t) * (n_tiles + 1), hipMemcpyHostToDevice, stream));
+    if (total) RT_HIP(c, hipMemcpyAsync(c->d_tile_entries, entries.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice, stream));
+    RT_HIP(c, hipStreamSynchronize(stream));
+    c->tiles.tile_start = c->d_tile_start;
+    c->tiles.entries = c->d_tile_entries;
+    c->tiles.tiles_x = tx;
+    c->tiles.enabled = 1u;
     return RT_OK;
 }
 
@@ -569,6 +640,11 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     g.always = c->d_grid_always;
     g.n_always = (uint32_t)always.size();
     g.enabled = 1u;
+    c->h_grid_spheres.resize(4 * (size_t)n);
+    for (uint32_t i = 0; i < n; ++i) {
+        c->h_grid_spheres[4 * i] = sph[i].x; c->h_grid_spheres[4 * i + 1] = sph[i].y; c->h_grid_spheres[4 * i + 2] = sph[i].z;
+        c->h_grid_spheres[4 * i + 3] = rg[i];
+    }
     return RT_OK;
 }
 
@@ -723,6 +799,7 @@ int rt_set_camera(rt_context* c, uint32_t width, uint32_t height, float z) {
     c->height = height;
     c->z = z;
     c->rects_dirty = true;
+    c->tiles_dirty = true;
     return RT_OK;
 }
 
@@ -861,6 +938,8 @@ void rt_destroy(rt_context* c) {
     if (c->d_grid_cell_start) (void)hipFree(c->d_grid_cell_start);
     if (c->d_grid_entries) (void)hipFree(c->d_grid_entries);
     if (c->d_grid_always) (void)hipFree(c->d_grid_always);
+    if (c->d_tile_start) (void)hipFree(c->d_tile_start);
+    if (c->d_tile_entries) (void)hipFree(c->d_tile_entries);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->d_out) (void)hipFree(c->d_out);

@@ -36,6 +36,14 @@ struct GridDesc {
     uint32_t enabled;
 };
 
+// screen tiles for pinhole primary rays (built on the host per camera, rt_api.cpp: build_screen_tiles)
+struct ScreenTiles {
+    const uint32_t* __restrict__ tile_start;  // tiles_x * tiles_y + 1 offsets
+    const uint32_t* __restrict__ entries;     // object indices, ascending inside a tile
+    uint32_t tiles_x;                         // tiles are 64 pixels wide, 8 rows tall
+    uint32_t enabled;
+};
+
 // order-free closest-hit update (see header comment); `cur_sphere` = the current winner is a sphere
 template <bool FUSED>
 __device__ __forceinline__ void closest_update_unordered(uint32_t type, float sx, float sy, float sz, float dx, float dy,

@@ -40,6 +40,7 @@ struct WavefrontBuffers {
     uint32_t* q_slice[2] = {nullptr, nullptr};     // survivors of a shadow slice (ping-pong)
     const HotPair* shadow_pairs = nullptr;         // size-sorted pair stream (owned by the context)
     GridDesc grid = {};                            // conservative grid (owned by the context); enabled = 0 -> brute force
+    ScreenTiles tiles = {};                        // per-screen-tile object lists for pinhole primary rays
     uint32_t* counts = nullptr;                    // 4 x uint32 device counters
     uint32_t* h_counts = nullptr;                  // 4 x uint32 pinned host mirror
     uint64_t capacity = 0;                         // n_local the buffers were sized for

@@ -45,6 +45,7 @@ struct WfParams {
     uint32_t* counts;     // [0] closest next, [1] any next, [2] shadow-slice survivors (device counters)
     const HotPair* shadow_pairs;  // pair stream sorted by decreasing size, for order-free shadow tests
     GridDesc grid;                // conservative uniform grid (enabled = 0: brute force)
+    ScreenTiles tiles;            // screen-tile object lists for pinhole primary rays
     uint32_t n_prev_closest, n_prev_any;
     int kernel;
     uint32_t count_rays;  // instrumentation on
@@ -198,6 +199,52 @@ __global__ __launch_bounds__(256) void wf_trace_closest_grid(const WfParams w, u
     if (w.count_rays) atomicAdd(&w.rp.counters->tests, (unsigned long long)tested);
 }
 
+// First round of a pinhole frame: a wave holds 64 consecutive pixels of one row, i.e. one 64x8 screen tile, and
+// walks that tile's object list with wave-uniform scalar loads (plus the always-list). Waves that straddle tiles
+// (ragged ends) fall back to the per-lane grid walk. Order-free tie rules, so the result is the same either way.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams w, uint32_t n_queue) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= n_queue) return;
+    const RenderParams& p = w.rp;
+    const uint64_t i = w.q_prev_closest[t];
+    const Ray ray = load_ray(w, i);
+    uint64_t g = i;
+    if (p.world > 1u) {
+        const uint64_t tile = i / p.tile_rays;
+        g = (tile * p.world + p.rank) * p.tile_rays + (i - tile * p.tile_rays);
+    }
+    const uint32_t row = (uint32_t)g / p.width, col = (uint32_t)g - row * p.width;
+    const uint32_t tile = (row >> 3) * w.tiles.tiles_x + (col >> 6);
+    const uint32_t first = __builtin_amdgcn_readfirstlane(tile);
+    float T = kMaxFloat;
+    int idx = -1;
+    uint32_t tested = 0;
+    if (__ballot(tile != first) == 0ull) {
+        bool cur_sphere = false;
+        const RT_CONST HotObjectC* hot = (const RT_CONST HotObjectC*)(p.scene.hot);
+        for (uint32_t a = 0; a < w.grid.n_always; ++a) {
+            const int k = (int)w.grid.always[a];
+            float sx, sy, sz, dx, dy, dz;
+            object_space_one<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz);
+            closest_update_unordered<FUSED>(hot[k].type, sx, sy, sz, dx, dy, dz, k, T, idx, cur_sphere);
+        }
+        const uint32_t e0 = w.tiles.tile_start[first], e1 = w.tiles.tile_start[first + 1];
+        tested = w.grid.n_always + (e1 - e0);
+        for (uint32_t e = e0; e < e1; ++e) {
+            const int k = (int)w.tiles.entries[e];
+            float sx, sy, sz, dx, dy, dz;
+            object_space_one<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz);
+            closest_update_unordered<FUSED>(hot[k].type, sx, sy, sz, dx, dy, dz, k, T, idx, cur_sphere);
+        }
+    } else {
+        closest_hit_grid<FUSED, true>(w.grid, p.scene.hot, ray, T, idx, tested);
+    }
+    F(w, F_RES_T, i) = T;
+    U(w, F_RES_I, i) = (uint32_t)idx;
+    if (w.count_rays) atomicAdd(&w.rp.counters->tests, (unsigned long long)tested);
+}
+
 template <bool FUSED>
 __global__ __launch_bounds__(256) void wf_trace_any_grid(const WfParams w, uint32_t n_queue) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -295,10 +342,8 @@ __device__ __forceinline__ void begin_shade(Ctx& c, const HitRec& h, bool primar
     c.reference += S.n_lights;
     if (S.n_lights == 0) { shade_done<KERNEL, FUSED>(c, h, primary, 0.f, 0.f, 0.f); return; }
     const bool forward = (KERNEL == 1) || S.literal;
-    F(c.w, F_SR, c.i) = 0.f; F(c.w, F_SG, c.i) = 0.f; F(c.w, F_SB, c.i) = 0.f;
-    F(c.w, F_DR, c.i) = 0.f; F(c.w, F_DG, c.i) = 0.f; F(c.w, F_DB, c.i) = 0.f;
-    F(c.w, F_AR, c.i) = 0.f; F(c.w, F_AG, c.i) = 0.f; F(c.w, F_AB, c.i) = 0.f;
-    F(c.w, F_CR, c.i) = 0.f; F(c.w, F_CG, c.i) = 0.f; F(c.w, F_CB, c.i) = 0.f;
+    // the carried light-loop terms start at zero: resume_shadow() knows the first light of a scan and does not
+    // read them, so nothing is written here
     emit_shadow<FUSED>(c, h, forward ? 0u : S.n_lights - 1u, primary ? PH_SHADOW_PRIMARY : PH_SHADOW_REFLECT);
 }
 
@@ -320,9 +365,11 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
     const LightRec L = S.lights[li];
     LightGeom g;
     light_geometry<FUSED>(L, h, nvx, nvy, nvz, vvx, vvy, vvz, g);
-    float sr = F(c.w, F_SR, i), sg = F(c.w, F_SG, i), sb = F(c.w, F_SB, i);
     const uint32_t phase = primary ? PH_SHADOW_PRIMARY : PH_SHADOW_REFLECT;
     const bool forward = (KERNEL == 1) || S.literal;
+    const bool first_of_scan = forward ? (li == 0u) : (li == S.n_lights - 1u);  // carried terms are still all zero
+    float sr = 0.f, sg = 0.f, sb = 0.f;
+    if (!first_of_scan) { sr = F(c.w, F_SR, i); sg = F(c.w, F_SG, i); sb = F(c.w, F_SB, i); }
     if (forward) {
         const float ar = amb.x * L.ambient.x, ag = amb.y * L.ambient.y, ab = amb.z * L.ambient.z;
         float dr, dg, db;
@@ -337,7 +384,8 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
             dr = 0.f; dg = 0.f; db = 0.f;
             sr = 0.f; sg = 0.f; sb = 0.f;
         }
-        float cr = F(c.w, F_CR, i), cg = F(c.w, F_CG, i), cb = F(c.w, F_CB, i);
+        float cr = 0.f, cg = 0.f, cb = 0.f;
+        if (!first_of_scan) { cr = F(c.w, F_CR, i); cg = F(c.w, F_CG, i); cb = F(c.w, F_CB, i); }
         if (KERNEL == 1) { cr = ((cr + ar) + dr) + sr; cg = ((cg + ag) + dg) + sg; cb = ((cb + ab) + db) + sb; }
         else { cr = (ar + dr) + sr; cg = (ag + dg) + sg; cb = (ab + db) + sb; }
         if (li + 1u < S.n_lights) {
@@ -350,8 +398,11 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
         return;
     }
     // backward scan (shade_last_light_wins)
-    float ar = F(c.w, F_AR, i), ag = F(c.w, F_AG, i), ab = F(c.w, F_AB, i);
-    float dr = F(c.w, F_DR, i), dg = F(c.w, F_DG, i), db = F(c.w, F_DB, i);
+    float ar = 0.f, ag = 0.f, ab = 0.f, dr = 0.f, dg = 0.f, db = 0.f;
+    if (!first_of_scan) {
+        ar = F(c.w, F_AR, i); ag = F(c.w, F_AG, i); ab = F(c.w, F_AB, i);
+        dr = F(c.w, F_DR, i); dg = F(c.w, F_DG, i); db = F(c.w, F_DB, i);
+    }
     bool need_specular = true;
     if (li == S.n_lights - 1u) {
         ar = amb.x * L.ambient.x; ag = amb.y * L.ambient.y; ab = amb.z * L.ambient.z;
@@ -370,6 +421,7 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
     if (need_specular && li > 0u) {
         F(c.w, F_AR, i) = ar; F(c.w, F_AG, i) = ag; F(c.w, F_AB, i) = ab;
         F(c.w, F_DR, i) = dr; F(c.w, F_DG, i) = dg; F(c.w, F_DB, i) = db;
+        F(c.w, F_SR, i) = sr; F(c.w, F_SG, i) = sg; F(c.w, F_SB, i) = sb;
         emit_shadow<FUSED>(c, h, li - 1u, phase);
     } else {
         shade_done<KERNEL, FUSED>(c, h, primary, (ar + dr) + sr, (ag + dg) + sg, (ab + db) + sb);
@@ -510,6 +562,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
     w.counts = buf.counts;
     w.shadow_pairs = buf.shadow_pairs;
     w.grid = buf.grid;
+    w.tiles = buf.tiles;
     w.q_closest = q[cur][0];
     w.q_any = q[cur][1];
     hipLaunchKernelGGL(wf_begin, dim3((uint32_t)((n + kResumeThreads - 1) / kResumeThreads)), dim3(kResumeThreads), 0, stream, w);
@@ -530,7 +583,9 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
         w.n_prev_any = na;
         const bool use_grid = w.grid.enabled && !w.rp.scene.literal;
         if (nc) {
-            if (use_grid) {
+            if (use_grid && first && w.tiles.enabled && w.rp.pinhole) {
+                hipLaunchKernelGGL((wf_trace_primary_tiles<FUSED>), grid_for(nc), dim3(256), 0, stream, w, nc);
+            } else if (use_grid) {
                 if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest_grid<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
                 else hipLaunchKernelGGL((wf_trace_closest_grid<FUSED, true>), grid_for(nc), dim3(256), 0, stream, w, nc);
             } else {
