@@ -313,14 +313,18 @@ int ensure_host_out(rt_context* c) {
     return RT_OK;
 }
 
-// Scenes with at least this many objects take the wavefront path unless a flag says otherwise: below it the
-// per-round state traffic and launches cost more than the leaner traversal loop saves.
-constexpr uint32_t kWavefrontMinObjects = 512;
+// Path choice unless a flag says otherwise. Measured at 2048^2 (scratch sweep, depth 3, 4 lights): the small-scene
+// kernel wins up to 64 objects (per-bundle culling), the wavefront path with the grid from ~100 objects on
+// (N=128: 1.4 vs 0.9 ms, N=512: 7.4 vs 1.3 ms). Without a usable grid the wavefront path only pays once the
+// traversal loop dwarfs its per-round state traffic.
+constexpr uint32_t kWavefrontMinObjects = 512;      // brute-force wavefront
+constexpr uint32_t kWavefrontGridMinObjects = 96;   // wavefront when the conservative grid is available
 
 bool use_wavefront(const rt_context* c) {
     if (c->flags & RT_FLAG_WAVEFRONT) return true;
     if (c->flags & RT_FLAG_MONOLITHIC) return false;
-    return c->n_objs >= kWavefrontMinObjects;
+    if (c->n_objs >= kWavefrontMinObjects) return true;
+    return c->n_objs >= kWavefrontGridMinObjects && c->grid.enabled && !(c->flags & RT_FLAG_LITERAL);
 }
 
 void free_wavefront(rt_context* c) {
@@ -781,7 +785,7 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         }
     }
 #undef RT_TRY
-    if (n_objs >= kWavefrontMinObjects || (flags & RT_FLAG_WAVEFRONT)) {
+    if (n_objs >= kWavefrontGridMinObjects || (flags & RT_FLAG_WAVEFRONT)) {
         rc = build_grid(c, static_cast<const rt_object_data*>(objs), n_objs);
         if (rc != RT_OK) return bail(rc);
     }
