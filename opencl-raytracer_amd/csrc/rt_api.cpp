@@ -68,6 +68,7 @@ struct rt_context {
     uint32_t* d_grid_cell_start = nullptr;
     uint32_t* d_grid_entries = nullptr;
     uint32_t* d_grid_always = nullptr;
+    float4* d_grid_entry_sphere = nullptr;
     std::vector<double> h_grid_spheres;     // per object: centre + grid radius (inf: always tested, < 0: never hit)
     uint32_t* d_tile_start = nullptr;       // screen tiles (64 x 8 pixels) -> objects a pinhole primary ray can reach
     uint32_t* d_tile_entries = nullptr;
@@ -628,6 +629,17 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
             RT_HIP(c, hipMalloc((void**)&c->d_grid_cell_start, sizeof(uint32_t) * (n_cells + 1)));
             RT_HIP(c, hipMalloc((void**)&c->d_grid_entries, sizeof(uint32_t) * (total + 1)));
             RT_HIP(c, hipMalloc((void**)&c->d_grid_always, sizeof(uint32_t) * (always.size() + 1)));
+            {   // per entry: the sphere the object was registered with (rounded outwards), for the kernels' pre-test
+                std::vector<float4> es(total);
+                for (size_t k = 0; k < total; ++k) {
+                    const uint32_t i = entries[k];
+                    const double cl = std::sqrt(sph[i].x * sph[i].x + sph[i].y * sph[i].y + sph[i].z * sph[i].z);
+                    const float r = std::nextafter((float)(rg[i] + 1e-6 * cl), std::numeric_limits<float>::infinity());
+                    es[k] = make_float4((float)sph[i].x, (float)sph[i].y, (float)sph[i].z, r);
+                }
+                RT_HIP(c, hipMalloc((void**)&c->d_grid_entry_sphere, sizeof(float4) * (total + 1)));
+                if (total) RT_HIP(c, hipMemcpy(c->d_grid_entry_sphere, es.data(), sizeof(float4) * total, hipMemcpyHostToDevice));
+            }
             RT_HIP(c, hipMemcpy(c->d_grid_cell_start, start.data(), sizeof(uint32_t) * (n_cells + 1), hipMemcpyHostToDevice));
             if (total) RT_HIP(c, hipMemcpy(c->d_grid_entries, entries.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
             if (!always.empty())
@@ -641,6 +653,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     g.nx = dim[0]; g.ny = dim[1]; g.nz = dim[2];
     g.cell_start = c->d_grid_cell_start;
     g.entries = c->d_grid_entries;
+    g.entry_sphere = c->d_grid_entry_sphere;
     g.always = c->d_grid_always;
     g.n_always = (uint32_t)always.size();
     g.enabled = 1u;
@@ -942,6 +955,7 @@ void rt_destroy(rt_context* c) {
     if (c->d_grid_cell_start) (void)hipFree(c->d_grid_cell_start);
     if (c->d_grid_entries) (void)hipFree(c->d_grid_entries);
     if (c->d_grid_always) (void)hipFree(c->d_grid_always);
+    if (c->d_grid_entry_sphere) (void)hipFree(c->d_grid_entry_sphere);
     if (c->d_tile_start) (void)hipFree(c->d_tile_start);
     if (c->d_tile_entries) (void)hipFree(c->d_tile_entries);
     if (c->d_lights) (void)hipFree(c->d_lights);

@@ -31,6 +31,7 @@ struct GridDesc {
     int nx, ny, nz;
     const uint32_t* __restrict__ cell_start;  // nx*ny*nz + 1 offsets into entries
     const uint32_t* __restrict__ entries;     // object indices, ascending inside a cell
+    const float4* __restrict__ entry_sphere;  // parallel to entries: the object's inflated bounding sphere (centre, R_grid)
     const uint32_t* __restrict__ always;      // objects every ray must test
     uint32_t n_always;
     uint32_t enabled;
@@ -59,6 +60,22 @@ __device__ __forceinline__ void closest_update_unordered(uint32_t type, float sx
     else if (t == T) take = sphere ? (!cur_sphere || k > index) : (!cur_sphere && k < index);
     else take = false;
     if (take) { T = t; index = k; cur_sphere = sphere; }
+}
+
+// Cheap conservative rejection of a grid candidate before its 52-byte matrix is fetched: does the ray's line
+// pass the object's INFLATED bounding sphere (the one the grid was built with, so all the reference's rounding is
+// already inside it), and is that sphere not entirely behind the ray origin? The test's own fp32 rounding
+// (~1e-6 |oc|^2 A on the discriminant) is covered by rejecting only below -8e-6 |oc|^2 A.
+__device__ __forceinline__ bool misses_bounding_sphere(const float4 s, const Ray& ray, float dd) {
+    const float ox = s.x - ray.sx, oy = s.y - ray.sy, oz = s.z - ray.sz;
+    const float oo = ox * ox + oy * oy + oz * oz;
+    const float od = ox * ray.dx + oy * ray.dy + oz * ray.dz;
+    const float c = oo - s.w * s.w;
+    const float disc = od * od - dd * c;
+    const float tol = 8.0e-6f * oo * dd;
+    if (disc < -tol) return true;                 // the line misses the sphere
+    if (od < 0.f && c > 1.0e-5f * oo) return true;  // centre behind the origin and the origin clearly outside
+    return false;                                 // (NaNs compare false: the candidate is tested)
 }
 
 // per-lane object test: the HotObject arrives through ordinary (divergent) vector loads

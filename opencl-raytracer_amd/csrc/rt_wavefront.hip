@@ -256,6 +256,119 @@ __global__ __launch_bounds__(256) void wf_trace_any_grid(const WfParams w, uint3
     if (w.count_rays) atomicAdd(&w.rp.counters->tests, (unsigned long long)tested);
 }
 
+// ---- grid traversal, persistent waves ----------------------------------------------------------------------------
+// The straightforward per-lane walk (one thread = one ray, nested cell / candidate loops) keeps only ~9 of 64
+// lanes busy (PMC: SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU): rays differ in length, cells in population, and a
+// finished lane idles until the longest ray of its wave is done. Here a wave owns a segment of kSegment
+// consecutive queue entries; a lane that finishes its ray immediately takes the next one of the segment (a
+// wave-uniform cursor, no atomics), and the walk is a single loop in which every lane does at most one cell fetch
+// and one candidate per trip. Same cells, same candidates, same order-free update -> same results.
+// (Tried and dropped: scheduling one phase per trip by the number of lanes waiting in each state - refill / step
+// / pre-test / full test - so that the full test only runs with half the wave ready: 2x SLOWER, the extra trips
+// and ballots cost more than the better packing of the expensive phase saves.)
+constexpr uint32_t kSegment = 512;
+
+template <bool FUSED, bool ANY>
+__global__ __launch_bounds__(256) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint64_t seg0 = (uint64_t)wave * kSegment;
+    if (seg0 >= n_queue) return;  // wave-uniform
+    const uint32_t seg_end = (uint32_t)((seg0 + kSegment < n_queue) ? seg0 + kSegment : n_queue);
+    uint32_t next = (uint32_t)seg0;  // wave-uniform cursor into the segment
+    const GridDesc& g = w.grid;
+    const HotObject* __restrict__ hot = w.rp.scene.hot;
+    const unsigned long long below = (1ull << lane) - 1ull;
+
+    int st = 0;            // 0 idle (needs a ray), 1 at a cell whose list has not been fetched, 2 testing candidates
+    uint32_t pix = 0;      // pixel whose ray this lane is tracing
+    Ray ray = {};
+    Walk wk = {};
+    uint32_t e = 0, e1 = 0;
+    float T = kMaxFloat, slack = 0.f, dd = 0.f;
+    int idx = -1;
+    bool cur_sphere = false;
+    unsigned long long tested = 0;
+
+    for (;;) {
+        // ---- hand out rays to idle lanes ----
+        const unsigned long long idle = __ballot(st == 0);
+        if (idle != 0ull && next < seg_end) {
+            const uint32_t mine = next + (uint32_t)__popcll(idle & below);
+            if (st == 0 && mine < seg_end) {
+                pix = queue[mine];
+                ray = load_ray(w, pix);
+                T = kMaxFloat; idx = -1; cur_sphere = false;
+                bool done = false;
+                for (uint32_t a = 0; a < g.n_always && !done; ++a) {  // objects every ray must test (usually none)
+                    const int k = (int)g.always[a];
+                    float sx, sy, sz, dx, dy, dz;
+                    uint32_t type;
+                    lane_object_space<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
+                    ++tested;
+                    if (ANY) done = occludes<FUSED>(type, sx, sy, sz, dx, dy, dz);
+                    else closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, k, T, idx, cur_sphere);
+                }
+                dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
+                const float len = __builtin_sqrtf(dd);
+                slack = len > 0.f ? 2.0f * g.cell / len : 3.0e38f;
+                if (!done) wk = walk_begin(g, ray, ANY ? 1.0f + slack : 3.0e38f);
+                if (done || !wk.alive) {  // occluded by an always-object, or the ray misses the grid box
+                    if (ANY) U(w, F_RES_I, pix) = done ? 0u : 1u;
+                    else { F(w, F_RES_T, pix) = T; U(w, F_RES_I, pix) = (uint32_t)idx; }
+                } else {
+                    st = 1;
+                }
+            }
+            next += (uint32_t)__popcll(idle);
+        }
+        if (__ballot(st != 0) == 0ull) {
+            if (next >= seg_end) break;
+            continue;
+        }
+        bool advance = false;
+        // ---- phase A: fetch the current cell's list ----
+        if (st == 1) {
+            const uint32_t c = ((uint32_t)wk.iz * (uint32_t)g.ny + (uint32_t)wk.iy) * (uint32_t)g.nx + (uint32_t)wk.ix;
+            e = g.cell_start[c];
+            e1 = g.cell_start[c + 1];
+            if (e < e1) st = 2;
+            else advance = true;
+        }
+        // ---- phase B: one candidate (also for a lane that has just fetched a non-empty cell) ----
+        if (st == 2) {
+            const float4 bound = g.entry_sphere[e];
+            const int k = (int)g.entries[e];
+            ++e;
+            if (!misses_bounding_sphere(bound, ray, dd)) {
+                float sx, sy, sz, dx, dy, dz;
+                uint32_t type;
+                lane_object_space<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
+                ++tested;
+                if (ANY) {
+                    if (occludes<FUSED>(type, sx, sy, sz, dx, dy, dz)) { U(w, F_RES_I, pix) = 0u; st = 0; }
+                } else {
+                    closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, k, T, idx, cur_sphere);
+                }
+            }
+            if (st == 2 && e == e1) advance = true;
+        }
+        // ---- step to the next cell, or finish the ray ----
+        if (advance) {
+            const bool inside = walk_next(g, wk);
+            const float limit = ANY ? 1.0f + slack : T + slack;
+            if (!inside || wk.t_enter > limit) {
+                if (ANY) U(w, F_RES_I, pix) = 1u;  // nothing in the way
+                else { F(w, F_RES_T, pix) = T; U(w, F_RES_I, pix) = (uint32_t)idx; }
+                st = 0;
+            } else {
+                st = 1;
+            }
+        }
+    }
+    if (w.count_rays && tested) atomicAdd(&w.rp.counters->tests, tested);
+}
+
 // Literal shadow test: the reference's full closest hit, then its `time >= 1 || time < 0` (:229).
 template <bool FUSED>
 __global__ __launch_bounds__(256) void wf_trace_any_literal(const WfParams w, uint32_t n_queue) {
@@ -547,6 +660,8 @@ constexpr uint32_t kMaxSlices = 16;
 
 // ---- host driver -----------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255u) / 256u)); }
+// one wave per kSegment queue entries, four waves per workgroup
+static inline dim3 persistent_grid(uint64_t n) { return dim3((uint32_t)((((n + kSegment - 1) / kSegment) + 3u) / 4u)); }
 
 size_t wavefront_state_bytes(uint64_t n_local) { return (size_t)F_COUNT * sizeof(float) * (size_t)n_local; }
 size_t wavefront_queue_bytes(uint64_t n_local) { return sizeof(uint32_t) * (size_t)n_local; }
@@ -587,7 +702,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
                 hipLaunchKernelGGL((wf_trace_primary_tiles<FUSED>), grid_for(nc), dim3(256), 0, stream, w, nc);
             } else if (use_grid) {
                 if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest_grid<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
-                else hipLaunchKernelGGL((wf_trace_closest_grid<FUSED, true>), grid_for(nc), dim3(256), 0, stream, w, nc);
+                else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, false>), persistent_grid(nc), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_closest, nc);
             } else {
                 if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
                 else hipLaunchKernelGGL((wf_trace_closest<FUSED, true>), grid_for(nc), dim3(256), 0, stream, w, nc);
@@ -599,7 +714,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
                 hipLaunchKernelGGL((wf_trace_any_literal<FUSED>), grid_for(na), dim3(256), 0, stream, w, na);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             } else if (use_grid) {
-                hipLaunchKernelGGL((wf_trace_any_grid<FUSED>), grid_for(na), dim3(256), 0, stream, w, na);
+                hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, true>), persistent_grid(na), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_any, na);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             } else {
                 // slices of >= kMinSlicePairs pairs (amortises each launch's pipeline fill), at most kMaxSlices
