@@ -266,7 +266,10 @@ __global__ __launch_bounds__(256) void wf_trace_any_grid(const WfParams w, uint3
 // (Tried and dropped: scheduling one phase per trip by the number of lanes waiting in each state - refill / step
 // / pre-test / full test - so that the full test only runs with half the wave ready: 2x SLOWER, the extra trips
 // and ballots cost more than the better packing of the expensive phase saves.)
-constexpr uint32_t kSegment = 512;
+#ifndef RT_SEGMENT
+#define RT_SEGMENT 256  // measured on the cfg4 frame: 128: 58.7 ms, 256: 57.8, 512: 64.1, 1024: 77.4, 2048: 103
+#endif
+constexpr uint32_t kSegment = RT_SEGMENT;
 
 template <bool FUSED, bool ANY>
 __global__ __launch_bounds__(256) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue) {

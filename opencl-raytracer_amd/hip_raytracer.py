@@ -56,7 +56,7 @@ def load_library(path: os.PathLike | None = None) -> ctypes.CDLL:
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = Path(path) if path else LIB_PATH
+    p = Path(path) if path else Path(os.environ.get("RT_LIB_OVERRIDE", LIB_PATH))  # override: A/B builds of the library
     if not p.exists():
         raise FileNotFoundError(
             f"{p} is missing - build it with `make -C opencl-raytracer_amd/csrc` (or __graft_entry__.build()); "
