@@ -9,7 +9,7 @@ equal the oracle's, which pins the hit/miss structure of every secondary ray.
 import numpy as np
 import pytest
 
-from helpers import (R, camera, compare_frames, count_float_mismatches, expected_full, fixture_names, load_fixture,
+from helpers import (R, camera, compare_frames, count_float_mismatches, expected_full, fixture_names, load_fixture, rotation,
                      random_scene, same_floats)
 
 pytestmark = pytest.mark.gpu
@@ -365,3 +365,42 @@ def test_device_resident_render_through_torch_plumbing():
     got = frame.cpu().numpy()
     srt.close()
     assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_grid_always_list_and_fallbacks(restatement):
+    """Objects as large as the scene go to the grid's always-tested list; non-affine matrices or primary rays with
+    start.w != 1 switch the large-scene path back to brute force. All of them must match the oracle."""
+    from helpers import instance
+    objs, lights = random_scene(500, 200, 3, seed=555, spread=10.0, zrange=(-50.0, -10.0))
+    huge = []
+    mv, inv = instance((0, -40, -30), None, (60, 60, 60))        # a sphere bigger than the whole cloud below it
+    huge.append(R.make_object(R.SPHERE, R.Material((.2, .2, .2), (.5, .5, .5), (.3, .3, .3), absorption=0.6), mv, inv))
+    mv, inv = instance((0, 0, -75), rotation((0, 1, 0), 0.3), (120, 120, 4))  # a wall behind everything
+    huge.append(R.make_object(R.BOX, R.Material((.1, .2, .3), (.4, .4, .4), (.6, .6, .6), absorption=0.4), mv, inv))
+    objs = np.concatenate([objs[:350], R.objects_array(huge), objs[350:]])
+    rays = camera.primary_rays(96, 64)
+    want = restatement[True].render("shade_and_reflect", objs, lights, rays, 3)
+    got = _grid_equals_brute(objs, lights, rays, 3)
+    assert compare_frames(got, want["out"]) <= RGB_ATOL
+    assert int((want["hit_index"] >= 0).sum()) == len(rays)  # the wall catches every ray
+
+    # non-affine: perturb the bottom row of one mvInverse -> grid must not be used, results still the oracle's
+    odd = objs.copy()
+    odd["mvInverse"][7][15] = np.float32(1.0000001)
+    want = restatement[True].render("shade_and_reflect", odd, lights, rays, 2)
+    with hip(odd, lights, rays, 2) as rt:
+        out = rt.Render()
+        assert rt.stats().wavefront == 1
+        st = rt.count_rays()
+    assert st.object_tests >= st.rays_traced * 100  # brute force: every ray saw hundreds of objects
+    assert compare_frames(out, want["out"]) <= RGB_ATOL and st.rays_reference == want["rays_ref"]
+
+    # primary rays with start.w != 1
+    wrays = rays.copy()
+    wrays["start"][::3, 3] = 0.75
+    want = restatement[True].render("shade_and_reflect", objs, lights, wrays, 2)
+    with hip(objs, lights, wrays, 2) as rt:
+        out = rt.Render()
+        t, idx = rt.render_aux()
+    assert np.array_equal(idx, want["hit_index"]) and same_floats(t, want["hit_t"])
+    assert compare_frames(out, want["out"]) <= RGB_ATOL
