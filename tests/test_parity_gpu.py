@@ -431,3 +431,37 @@ def test_config5_base_rounded_cube_8192_properties(restatement):
         want = restatement[True].render("shade_and_reflect", objs, lights, rays, 5)["out"]
         assert compare_frames(first[k], want) <= RGB_ATOL
         assert np.array_equal(np.any(first[k][:, :3] != 0, axis=1), np.any(want[:, :3] != 0, axis=1))
+
+
+@pytest.mark.parametrize("seed", list(range(300, 324)))
+def test_randomised_configurations_vs_oracle(seed, restatement):
+    """Seeded sweep over scene size, primitive mix, light count / kind, depth, kernel, arithmetic flavour, path and
+    ray source; every combination against the oracle (index, t, ray accounting exact; RGB <= 1e-5)."""
+    rng = np.random.default_rng(seed)
+    n_s, n_b = int(rng.integers(0, 30)), int(rng.integers(0, 20))
+    if n_s + n_b == 0:
+        n_s = 1
+    n_l = int(rng.integers(0, 5))
+    objs, lights = random_scene(n_s, n_b, n_l, seed=seed, directional_lights=int(rng.integers(0, n_l + 1)) if n_l else 0,
+                                spread=float(rng.uniform(3, 9)), nonuniform=bool(rng.integers(0, 2)))
+    w, h = int(rng.integers(9, 70)), int(rng.integers(5, 40))
+    depth = int(rng.integers(0, 6))
+    kernel = ["hittest", "shade", "shade_and_reflect"][int(rng.integers(0, 3))]
+    fused = bool(rng.integers(0, 2))
+    path = ["monolithic", "wavefront"][int(rng.integers(0, 2))]
+    rays = camera.primary_rays(w, h)
+    if rng.integers(0, 3) == 0:  # arbitrary ray list instead of the pinhole grid
+        rays = rays.copy()
+        rays["start"][:, :3] = rng.uniform(-1, 1, (len(rays), 3)).astype(np.float32)
+    want = restatement[fused].render(kernel, objs, lights, rays, depth)
+    with hip(objs, lights, rays, depth, kernel=kernel, fused=fused, path=path, literal=bool(rng.integers(0, 4) == 0),
+             grid=bool(rng.integers(0, 4) != 0)) as rt:
+        out = rt.Render()
+        t, idx = rt.render_aux()
+        st = rt.count_rays()
+    assert np.array_equal(idx, want["hit_index"]) and same_floats(t, want["hit_t"])
+    assert st.rays_reference == want["rays_ref"]
+    if kernel == "hittest":
+        assert same_floats(out, want["out"])
+    else:
+        assert compare_frames(out, want["out"]) <= RGB_ATOL
