@@ -327,7 +327,7 @@ def main():
             culled = not (args.no_grid or args.literal)
             out["roofline"] = {"bound": "valu", "achieved": valu / 1e12, "peak": VALU_PEAK_LANE_OPS * world / 1e12,
                                "unit": "T lane-instr/s", "frac": valu / (VALU_PEAK_LANE_OPS * world), "traffic": None,
-                               "kernel": ("rt::wf_trace_closest_grid + rt::wf_trace_any_grid" if culled else
+                               "kernel": ("rt::wf_trace_grid_persistent<closest|any> + rt::wf_trace_primary_tiles" if culled else
                                           "rt::wf_trace_closest + rt::wf_trace_any_slice") + " (+ wf_resume, wf_begin)",
                                "kernel_ms": kernel_ms, "object_tests": tests,
                                "tests_per_s": tests / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0, "hbm": hbm}

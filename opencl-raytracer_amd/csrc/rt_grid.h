@@ -216,39 +216,4 @@ __device__ __forceinline__ void closest_hit_grid(const GridDesc& g, const HotObj
     }
 }
 
-// Any accepted candidate with t < 1 through the grid. Same answer as any_hit_before_one() over all objects.
-template <bool FUSED>
-__device__ __forceinline__ bool any_hit_grid(const GridDesc& g, const HotObject* __restrict__ hot, const Ray& ray,
-                                             uint32_t& tested) {
-    tested = 0;
-    for (uint32_t a = 0; a < g.n_always; ++a) {
-        ++tested;
-        const int k = (int)g.always[a];
-        float sx, sy, sz, dx, dy, dz;
-        uint32_t type;
-        lane_object_space<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
-        if (occludes<FUSED>(type, sx, sy, sz, dx, dy, dz)) return true;
-    }
-    // the segment up to the light, plus two cells of slack past t = 1
-    const float len = __builtin_sqrtf(ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz);
-    const float slack = len > 0.f ? 2.0f * g.cell / len : 3.0e38f;
-    Walk w = walk_begin(g, ray, 1.0f + slack);
-    if (!w.alive) return false;
-    for (;;) {
-        const uint32_t c = ((uint32_t)w.iz * (uint32_t)g.ny + (uint32_t)w.iy) * (uint32_t)g.nx + (uint32_t)w.ix;
-        const uint32_t e0 = g.cell_start[c], e1 = g.cell_start[c + 1];
-        for (uint32_t e = e0; e < e1; ++e) {
-            const int k = (int)g.entries[e];
-            float sx, sy, sz, dx, dy, dz;
-            uint32_t type;
-            ++tested;
-            lane_object_space<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
-            if (occludes<FUSED>(type, sx, sy, sz, dx, dy, dz)) return true;
-        }
-        if (!walk_next(g, w)) break;
-        if (w.t_enter > 1.0f + slack) break;
-    }
-    return false;
-}
-
 }  // namespace rt

@@ -182,8 +182,9 @@ __global__ __launch_bounds__(256) void wf_trace_closest(const WfParams w, uint32
         atomicAdd(&w.rp.counters->tests, 2ull * w.rp.scene.n_pairs * lanes);
 }
 
-// The same two traversals through the conservative grid (rt_grid.h): identical results, a few hundred
-// candidate tests per ray instead of one per object.
+// Closest hit through the conservative grid (rt_grid.h), one thread = one ray: identical results, a few dozen
+// candidate tests per ray instead of one per object. Used for first-round rays that are not a pinhole grid
+// (direction.w may be non-zero); every other ray goes through wf_trace_grid_persistent below.
 template <bool FUSED, bool DW0>
 __global__ __launch_bounds__(256) void wf_trace_closest_grid(const WfParams w, uint32_t n_queue) {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
@@ -242,17 +243,6 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams w, 
     }
     F(w, F_RES_T, i) = T;
     U(w, F_RES_I, i) = (uint32_t)idx;
-    if (w.count_rays) atomicAdd(&w.rp.counters->tests, (unsigned long long)tested);
-}
-
-template <bool FUSED>
-__global__ __launch_bounds__(256) void wf_trace_any_grid(const WfParams w, uint32_t n_queue) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n_queue) return;
-    const uint64_t i = w.q_prev_any[t];
-    const Ray ray = load_ray(w, i);
-    uint32_t tested = 0;
-    U(w, F_RES_I, i) = any_hit_grid<FUSED>(w.grid, w.rp.scene.hot, ray, tested) ? 0u : 1u;
     if (w.count_rays) atomicAdd(&w.rp.counters->tests, (unsigned long long)tested);
 }
 
