@@ -66,6 +66,7 @@ struct rt_context {
 
     rt::GridDesc grid = {};                 // device pointers owned by this context
     uint32_t* d_grid_cell_start = nullptr;
+    rt::GridCell* d_grid_cells = nullptr;
     uint32_t* d_grid_entries = nullptr;
     uint32_t* d_grid_always = nullptr;
     float4* d_grid_entry_sphere = nullptr;
@@ -639,6 +640,17 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
                 }
                 RT_HIP(c, hipMalloc((void**)&c->d_grid_entry_sphere, sizeof(float4) * (total + 1)));
                 if (total) RT_HIP(c, hipMemcpy(c->d_grid_entry_sphere, es.data(), sizeof(float4) * total, hipMemcpyHostToDevice));
+                std::vector<rt::GridCell> cells(n_cells);
+                for (size_t k = 0; k < n_cells; ++k) {
+                    rt::GridCell& gc = cells[k];
+                    gc.start = start[k];
+                    gc.count = start[k + 1] - start[k];
+                    gc.pad0 = gc.pad1 = 0;
+                    for (uint32_t j = 0; j < rt::kCellInline; ++j)
+                        gc.sphere[j] = j < gc.count ? es[start[k] + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                RT_HIP(c, hipMalloc((void**)&c->d_grid_cells, sizeof(rt::GridCell) * n_cells));
+                RT_HIP(c, hipMemcpy(c->d_grid_cells, cells.data(), sizeof(rt::GridCell) * n_cells, hipMemcpyHostToDevice));
             }
             RT_HIP(c, hipMemcpy(c->d_grid_cell_start, start.data(), sizeof(uint32_t) * (n_cells + 1), hipMemcpyHostToDevice));
             if (total) RT_HIP(c, hipMemcpy(c->d_grid_entries, entries.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
@@ -652,6 +664,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     g.inv_cell = 1.0f / cellf;
     g.nx = dim[0]; g.ny = dim[1]; g.nz = dim[2];
     g.cell_start = c->d_grid_cell_start;
+    g.cells = c->d_grid_cells;
     g.entries = c->d_grid_entries;
     g.entry_sphere = c->d_grid_entry_sphere;
     g.always = c->d_grid_always;
@@ -953,6 +966,7 @@ void rt_destroy(rt_context* c) {
     if (c->d_cold) (void)hipFree(c->d_cold);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
     if (c->d_grid_cell_start) (void)hipFree(c->d_grid_cell_start);
+    if (c->d_grid_cells) (void)hipFree(c->d_grid_cells);
     if (c->d_grid_entries) (void)hipFree(c->d_grid_entries);
     if (c->d_grid_always) (void)hipFree(c->d_grid_always);
     if (c->d_grid_entry_sphere) (void)hipFree(c->d_grid_entry_sphere);

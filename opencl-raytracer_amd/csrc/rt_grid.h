@@ -24,12 +24,24 @@
 
 namespace rt {
 
+// One 64-byte record per cell: where its list starts, how long it is, and copies of the first three pre-test
+// spheres - for most cells everything a passing ray looks at, in ONE cache line (the separate offset / sphere /
+// index arrays cost three lines per visited cell, and the walk is bound by L1/L2 request traffic).
+constexpr uint32_t kCellInline = 3;
+struct alignas(64) GridCell {
+    uint32_t start;   // first entry of the cell in entries / entry_sphere
+    uint32_t count;
+    uint32_t pad0, pad1;
+    float4 sphere[kCellInline];  // = entry_sphere[start .. start + 2]
+};
+
 struct GridDesc {
     float lox, loy, loz;        // grid origin (view space)
     float inv_cell;             // 1 / cell edge
     float cell;                 // cell edge
     int nx, ny, nz;
     const uint32_t* __restrict__ cell_start;  // nx*ny*nz + 1 offsets into entries
+    const GridCell* __restrict__ cells;       // nx*ny*nz records (the persistent walk reads these instead of cell_start)
     const uint32_t* __restrict__ entries;     // object indices, ascending inside a cell
     const float4* __restrict__ entry_sphere;  // parallel to entries: the object's inflated bounding sphere (centre, R_grid)
     const uint32_t* __restrict__ always;      // objects every ray must test
@@ -109,6 +121,9 @@ struct Walk {
     bool alive;
 };
 
+// The walk's own arithmetic uses the hardware reciprocal (1 ulp) instead of IEEE division: t values are only used
+// to order cell crossings, and their error (~1e-7 relative, i.e. < 1e-4 of a cell over the whole scene) sits far
+// inside the 0.01-cell slack every registered radius carries for exactly this purpose.
 __device__ __forceinline__ Walk walk_begin(const GridDesc& g, const Ray& ray, float t_limit) {
     Walk w;
     w.alive = false;
@@ -120,23 +135,21 @@ __device__ __forceinline__ Walk walk_begin(const GridDesc& g, const Ray& ray, fl
     // slab clip against the grid box, [t0, t1] subset of [0, t_limit]
     float t0 = 0.f, t1 = t_limit;
     const float big = 3.0e38f;
+    const float invx = __builtin_amdgcn_rcpf(dx), invy = __builtin_amdgcn_rcpf(dy), invz = __builtin_amdgcn_rcpf(dz);
     {
-        const float inv = 1.0f / dx;
-        float a = (g.lox - ox) * inv, b = (hix - ox) * inv;
+        float a = (g.lox - ox) * invx, b = (hix - ox) * invx;
         if (dx == 0.f) { a = (ox < g.lox || ox > hix) ? big : -big; b = (ox < g.lox || ox > hix) ? -big : big; }
         t0 = __builtin_fmaxf(t0, __builtin_fminf(a, b));
         t1 = __builtin_fminf(t1, __builtin_fmaxf(a, b));
     }
     {
-        const float inv = 1.0f / dy;
-        float a = (g.loy - oy) * inv, b = (hiy - oy) * inv;
+        float a = (g.loy - oy) * invy, b = (hiy - oy) * invy;
         if (dy == 0.f) { a = (oy < g.loy || oy > hiy) ? big : -big; b = (oy < g.loy || oy > hiy) ? -big : big; }
         t0 = __builtin_fmaxf(t0, __builtin_fminf(a, b));
         t1 = __builtin_fminf(t1, __builtin_fmaxf(a, b));
     }
     {
-        const float inv = 1.0f / dz;
-        float a = (g.loz - oz) * inv, b = (hiz - oz) * inv;
+        float a = (g.loz - oz) * invz, b = (hiz - oz) * invz;
         if (dz == 0.f) { a = (oz < g.loz || oz > hiz) ? big : -big; b = (oz < g.loz || oz > hiz) ? -big : big; }
         t0 = __builtin_fmaxf(t0, __builtin_fminf(a, b));
         t1 = __builtin_fminf(t1, __builtin_fmaxf(a, b));
@@ -156,12 +169,12 @@ __device__ __forceinline__ Walk walk_begin(const GridDesc& g, const Ray& ray, fl
     const float wallx = g.lox + g.cell * (float)(ix + (dx > 0.f ? 1 : 0));
     const float wally = g.loy + g.cell * (float)(iy + (dy > 0.f ? 1 : 0));
     const float wallz = g.loz + g.cell * (float)(iz + (dz > 0.f ? 1 : 0));
-    w.tx = dx != 0.f ? (wallx - ox) / dx : big;
-    w.ty = dy != 0.f ? (wally - oy) / dy : big;
-    w.tz = dz != 0.f ? (wallz - oz) / dz : big;
-    w.dtx = dx != 0.f ? g.cell / __builtin_fabsf(dx) : big;
-    w.dty = dy != 0.f ? g.cell / __builtin_fabsf(dy) : big;
-    w.dtz = dz != 0.f ? g.cell / __builtin_fabsf(dz) : big;
+    w.tx = dx != 0.f ? (wallx - ox) * invx : big;
+    w.ty = dy != 0.f ? (wally - oy) * invy : big;
+    w.tz = dz != 0.f ? (wallz - oz) * invz : big;
+    w.dtx = dx != 0.f ? g.cell * __builtin_fabsf(invx) : big;
+    w.dty = dy != 0.f ? g.cell * __builtin_fabsf(invy) : big;
+    w.dtz = dz != 0.f ? g.cell * __builtin_fabsf(invz) : big;
     w.t_enter = t0;
     w.alive = true;
     return w;

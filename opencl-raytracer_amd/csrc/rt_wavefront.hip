@@ -23,7 +23,7 @@ namespace rt {
 
 // ---- per-pixel state, struct-of-arrays: field f of pixel i at st[f * n + i] ------------------------------------
 enum : uint32_t {
-    F_SX, F_SY, F_SZ, F_SW, F_DX, F_DY, F_DZ, F_DW,          // the ray in flight (also needed to materialise its hit)
+    F_SX, F_SY, F_SZ, F_SW, F_DX, F_DY, F_DZ, F_DW,          // the ray in flight: ONE 32-byte record per pixel (store_ray)
     F_RES_T, F_RES_I,                                          // trace result: t / index, or occluded flag
     F_PX, F_PY, F_PZ, F_PW, F_NX, F_NY, F_NZ, F_RX, F_RY, F_RZ, F_HIDX,  // hit being shaded
     F_LI,                                                      // light index of the shadow ray in flight
@@ -56,14 +56,20 @@ __device__ __forceinline__ uint32_t& U(const WfParams& w, uint32_t f, uint64_t i
     return reinterpret_cast<uint32_t*>(w.st)[(uint64_t)f * w.rp.n_local + i];
 }
 
+// The ray in flight is the one record the trace kernels read per lane at scattered pixel ids (a lane takes a new
+// ray whenever its old one ends), so it is kept as one 32-byte record per pixel in the space of the first eight
+// fields: two 16-byte loads from one cache line instead of eight 4-byte loads from eight lines.
 __device__ __forceinline__ void store_ray(const WfParams& w, uint64_t i, const Ray& r) {
-    F(w, F_SX, i) = r.sx; F(w, F_SY, i) = r.sy; F(w, F_SZ, i) = r.sz; F(w, F_SW, i) = r.sw;
-    F(w, F_DX, i) = r.dx; F(w, F_DY, i) = r.dy; F(w, F_DZ, i) = r.dz; F(w, F_DW, i) = r.dw;
+    float4* slot = reinterpret_cast<float4*>(w.st) + 2 * i;
+    slot[0] = make_float4(r.sx, r.sy, r.sz, r.sw);
+    slot[1] = make_float4(r.dx, r.dy, r.dz, r.dw);
 }
 __device__ __forceinline__ Ray load_ray(const WfParams& w, uint64_t i) {
+    const float4* slot = reinterpret_cast<const float4*>(w.st) + 2 * i;
+    const float4 s = slot[0], d = slot[1];
     Ray r;
-    r.sx = F(w, F_SX, i); r.sy = F(w, F_SY, i); r.sz = F(w, F_SZ, i); r.sw = F(w, F_SW, i);
-    r.dx = F(w, F_DX, i); r.dy = F(w, F_DY, i); r.dz = F(w, F_DZ, i); r.dw = F(w, F_DW, i);
+    r.sx = s.x; r.sy = s.y; r.sz = s.z; r.sw = s.w;
+    r.dx = d.x; r.dy = d.y; r.dz = d.z; r.dw = d.w;
     return r;
 }
 __device__ __forceinline__ void store_hit(const WfParams& w, uint64_t i, const HitRec& h) {
@@ -261,37 +267,55 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams w, 
 #endif
 constexpr uint32_t kSegment = RT_SEGMENT;
 
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 8  // new rays are handed out once this many lanes are idle (setting a ray up is ~150 instructions)
+#endif
+#ifndef RT_DEFER_PENDING
+#define RT_DEFER_PENDING 16  // run the exact tests once this many lanes hold a candidate ...
+#endif
+#ifndef RT_DEFER_STUCK_SHIFT
+#define RT_DEFER_STUCK_SHIFT 2  // ... or once a quarter of the live lanes cannot move without theirs
+#endif
+
+// One segment of a queue, traced by one wave. A candidate that passes the 16-byte pre-test is not tested on the
+// spot: the lane parks it (`pend`) and keeps walking; the reference's exact test - a 52-byte gather and ~100
+// instructions - runs for the whole wave when enough lanes hold one (or are stuck behind theirs), so it executes
+// with tens of lanes instead of the 3-5 that happen to need it in any single trip. The closest-hit update is
+// order-free and T only ever shrinks, so a late update can only make a lane look at MORE cells than necessary.
 template <bool FUSED, bool ANY>
-__global__ __launch_bounds__(256) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue) {
+__device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t seg0,
+                                              uint32_t seg_len, uint32_t seg_stride, uint32_t n_queue, unsigned long long& tested) {
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
-    const uint64_t seg0 = (uint64_t)wave * kSegment;
-    if (seg0 >= n_queue) return;  // wave-uniform
-    const uint32_t seg_end = (uint32_t)((seg0 + kSegment < n_queue) ? seg0 + kSegment : n_queue);
-    uint32_t next = (uint32_t)seg0;  // wave-uniform cursor into the segment
+    // the wave's share of the queue: runs of seg_len entries starting at seg0, seg0 + seg_stride, ...
+    uint32_t next = seg0;  // wave-uniform cursor into the current run
+    uint32_t run0 = seg0;
+    uint32_t seg_end = (n_queue - seg0 < seg_len) ? n_queue : seg0 + seg_len;
     const GridDesc& g = w.grid;
     const HotObject* __restrict__ hot = w.rp.scene.hot;
     const unsigned long long below = (1ull << lane) - 1ull;
 
-    int st = 0;            // 0 idle (needs a ray), 1 at a cell whose list has not been fetched, 2 testing candidates
+    int st = 0;            // 0 idle (needs a ray), 1 at a cell whose list has not been fetched, 2 walking a list, 3 walk over
     uint32_t pix = 0;      // pixel whose ray this lane is tracing
     Ray ray = {};
     Walk wk = {};
-    uint32_t e = 0, e1 = 0;
+    uint32_t e = 0, e1 = 0;      // the current cell's list: next entry, end
+    uint32_t cj = 0;             // ... and where the next entry's sphere sits inside the cell record (>= kCellInline: not)
+    const GridCell* cellp = nullptr;
     float T = kMaxFloat, slack = 0.f, dd = 0.f;
     int idx = -1;
     bool cur_sphere = false;
-    unsigned long long tested = 0;
+    bool pend = false;     // a candidate that passed the pre-test and awaits the exact test
+    uint32_t pend_e = 0;
 
     for (;;) {
         // ---- hand out rays to idle lanes ----
         const unsigned long long idle = __ballot(st == 0);
-        if (idle != 0ull && next < seg_end) {
+        if (next < seg_end && ((uint32_t)__popcll(idle) >= (uint32_t)RT_REFILL_MIN || idle == ~0ull)) {
             const uint32_t mine = next + (uint32_t)__popcll(idle & below);
             if (st == 0 && mine < seg_end) {
                 pix = queue[mine];
                 ray = load_ray(w, pix);
-                T = kMaxFloat; idx = -1; cur_sphere = false;
+                T = kMaxFloat; idx = -1; cur_sphere = false; pend = false;
                 bool done = false;
                 for (uint32_t a = 0; a < g.n_always && !done; ++a) {  // objects every ray must test (usually none)
                     const int k = (int)g.always[a];
@@ -303,8 +327,7 @@ __global__ __launch_bounds__(256) void wf_trace_grid_persistent(const WfParams w
                     else closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, k, T, idx, cur_sphere);
                 }
                 dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
-                const float len = __builtin_sqrtf(dd);
-                slack = len > 0.f ? 2.0f * g.cell / len : 3.0e38f;
+                slack = dd > 0.f ? 2.0f * g.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
                 if (!done) wk = walk_begin(g, ray, ANY ? 1.0f + slack : 3.0e38f);
                 if (done || !wk.alive) {  // occluded by an always-object, or the ray misses the grid box
                     if (ANY) U(w, F_RES_I, pix) = done ? 0u : 1u;
@@ -314,51 +337,94 @@ __global__ __launch_bounds__(256) void wf_trace_grid_persistent(const WfParams w
                 }
             }
             next += (uint32_t)__popcll(idle);
+            if (next >= seg_end && (uint64_t)run0 + seg_stride < n_queue) {  // on to the wave's next run
+                run0 += seg_stride;
+                next = run0;
+                seg_end = (n_queue - run0 < seg_len) ? n_queue : run0 + seg_len;
+            }
         }
-        if (__ballot(st != 0) == 0ull) {
+        const unsigned long long live = __ballot(st != 0);
+        if (live == 0ull) {
             if (next >= seg_end) break;
             continue;
         }
-        bool advance = false;
+        bool advance = false, blocked = false;
         // ---- phase A: fetch the current cell's list ----
         if (st == 1) {
             const uint32_t c = ((uint32_t)wk.iz * (uint32_t)g.ny + (uint32_t)wk.iy) * (uint32_t)g.nx + (uint32_t)wk.ix;
-            e = g.cell_start[c];
-            e1 = g.cell_start[c + 1];
+            cellp = g.cells + c;
+            const uint2 hdr = *reinterpret_cast<const uint2*>(cellp);
+            e = hdr.x;
+            e1 = hdr.x + hdr.y;
+            cj = 0;
+#ifdef RT_CELL_LAZY
+            if (e < e1) st = 4;   // first candidate next trip (its line is on the way)
+#else
             if (e < e1) st = 2;
+#endif
             else advance = true;
         }
-        // ---- phase B: one candidate (also for a lane that has just fetched a non-empty cell) ----
+        // ---- phase B: pre-test one candidate (also for a lane that has just fetched a non-empty cell) ----
         if (st == 2) {
-            const float4 bound = g.entry_sphere[e];
-            const int k = (int)g.entries[e];
-            ++e;
-            if (!misses_bounding_sphere(bound, ray, dd)) {
-                float sx, sy, sz, dx, dy, dz;
-                uint32_t type;
-                lane_object_space<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
-                ++tested;
-                if (ANY) {
-                    if (occludes<FUSED>(type, sx, sy, sz, dx, dy, dz)) { U(w, F_RES_I, pix) = 0u; st = 0; }
-                } else {
-                    closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, k, T, idx, cur_sphere);
-                }
+            const float4* sp = (cj < kCellInline) ? &cellp->sphere[cj] : &g.entry_sphere[e];
+            const float4 bound = *sp;
+            const bool pass = !misses_bounding_sphere(bound, ray, dd);
+            if (pass && pend) {
+                blocked = true;  // one parking slot: wait for the exact tests
+            } else {
+                if (pass) { pend = true; pend_e = e; }
+                ++e; ++cj;
+                if (e == e1) advance = true;
             }
-            if (st == 2 && e == e1) advance = true;
         }
-        // ---- step to the next cell, or finish the ray ----
+#ifdef RT_CELL_LAZY
+        if (st == 4) st = 2;
+#endif
+        // ---- step to the next cell, or end the walk ----
         if (advance) {
             const bool inside = walk_next(g, wk);
             const float limit = ANY ? 1.0f + slack : T + slack;
-            if (!inside || wk.t_enter > limit) {
-                if (ANY) U(w, F_RES_I, pix) = 1u;  // nothing in the way
-                else { F(w, F_RES_T, pix) = T; U(w, F_RES_I, pix) = (uint32_t)idx; }
-                st = 0;
-            } else {
-                st = 1;
+            st = (!inside || wk.t_enter > limit) ? 3 : 1;
+        }
+        // ---- the exact tests, when enough lanes wait for them ----
+        const unsigned long long pending = __ballot(pend);
+        if (pending != 0ull) {
+            const unsigned long long stuck = __ballot(pend && (blocked || st == 3));
+            const uint32_t n_live = (uint32_t)__popcll(live);
+            if ((uint32_t)__popcll(pending) >= (uint32_t)RT_DEFER_PENDING ||
+                ((uint32_t)__popcll(stuck) << RT_DEFER_STUCK_SHIFT) >= n_live) {
+                if (pend) {
+                    float sx, sy, sz, dx, dy, dz;
+                    uint32_t type;
+                    const int pend_k = (int)g.entries[pend_e];
+                    lane_object_space<FUSED, true>(hot + pend_k, ray, sx, sy, sz, dx, dy, dz, type);
+                    ++tested;
+                    pend = false;
+                    if (ANY) {
+                        if (occludes<FUSED>(type, sx, sy, sz, dx, dy, dz)) { U(w, F_RES_I, pix) = 0u; st = 0; }
+                    } else {
+                        closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, pend_k, T, idx, cur_sphere);
+                    }
+                }
             }
         }
+        // ---- a finished walk with nothing parked: the ray is done ----
+        if (st == 3 && !pend) {
+            if (ANY) U(w, F_RES_I, pix) = 1u;  // nothing in the way
+            else { F(w, F_RES_T, pix) = T; U(w, F_RES_I, pix) = (uint32_t)idx; }
+            st = 0;
+        }
     }
+}
+
+template <bool FUSED, bool ANY>
+__global__ __launch_bounds__(256) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue) {
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * 256u) >> 6;
+    const uint64_t seg0 = (uint64_t)wave * kSegment;
+    if (seg0 >= n_queue) return;  // wave-uniform
+    unsigned long long tested = 0;
+    trace_segment<FUSED, ANY>(w, queue, (uint32_t)seg0, kSegment, n_waves * kSegment, n_queue, tested);
     if (w.count_rays && tested) atomicAdd(&w.rp.counters->tests, tested);
 }
 
@@ -654,7 +720,14 @@ constexpr uint32_t kMaxSlices = 16;
 // ---- host driver -----------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255u) / 256u)); }
 // one wave per kSegment queue entries, four waves per workgroup
-static inline dim3 persistent_grid(uint64_t n) { return dim3((uint32_t)((((n + kSegment - 1) / kSegment) + 3u) / 4u)); }
+#ifndef RT_MAX_WAVES
+#define RT_MAX_WAVES 100000000
+#endif
+static inline dim3 persistent_grid(uint64_t n) {
+    uint64_t waves = (n + kSegment - 1) / kSegment;
+    if (waves > (uint64_t)RT_MAX_WAVES) waves = RT_MAX_WAVES;
+    return dim3((uint32_t)((waves + 3u) / 4u));
+}
 
 size_t wavefront_state_bytes(uint64_t n_local) { return (size_t)F_COUNT * sizeof(float) * (size_t)n_local; }
 size_t wavefront_queue_bytes(uint64_t n_local) { return sizeof(uint32_t) * (size_t)n_local; }
