@@ -372,7 +372,7 @@ int ensure_wavefront(rt_context* c) {
         RT_HIP(c, hipMalloc((void**)&b.q_any[i], rt::wavefront_queue_bytes(n)));
         RT_HIP(c, hipMalloc((void**)&b.q_slice[i], rt::wavefront_queue_bytes(n)));
     }
-    RT_HIP(c, hipMalloc((void**)&b.counts, 4 * sizeof(uint32_t)));
+    RT_HIP(c, hipMalloc((void**)&b.counts, 8 * sizeof(uint32_t)));  // 4 queue counters + 2 run-ticket counters
     RT_HIP(c, hipHostMalloc((void**)&b.h_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
     b.shadow_pairs = c->d_shadow_pairs;
     b.grid = c->grid;

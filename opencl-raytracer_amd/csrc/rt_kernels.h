@@ -41,7 +41,7 @@ struct WavefrontBuffers {
     const HotPair* shadow_pairs = nullptr;         // size-sorted pair stream (owned by the context)
     GridDesc grid = {};                            // conservative grid (owned by the context); enabled = 0 -> brute force
     ScreenTiles tiles = {};                        // per-screen-tile object lists for pinhole primary rays
-    uint32_t* counts = nullptr;                    // 4 x uint32 device counters
+    uint32_t* counts = nullptr;                    // 4 queue counters + 2 run-ticket counters of the grid walk
     uint32_t* h_counts = nullptr;                  // 4 x uint32 pinned host mirror
     uint64_t capacity = 0;                         // n_local the buffers were sized for
 };

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams w, 
 // / pre-test / full test - so that the full test only runs with half the wave ready: 2x SLOWER, the extra trips
 // and ballots cost more than the better packing of the expensive phase saves.)
 #ifndef RT_SEGMENT
-#define RT_SEGMENT 256  // measured on the cfg4 frame: 128: 58.7 ms, 256: 57.8, 512: 64.1, 1024: 77.4, 2048: 103
+#define RT_SEGMENT 64  // queue entries per run
 #endif
 constexpr uint32_t kSegment = RT_SEGMENT;
 
@@ -283,13 +283,36 @@ constexpr uint32_t kSegment = RT_SEGMENT;
 // with tens of lanes instead of the 3-5 that happen to need it in any single trip. The closest-hit update is
 // order-free and T only ever shrinks, so a late update can only make a lane look at MORE cells than necessary.
 template <bool FUSED, bool ANY>
-__device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t seg0,
-                                              uint32_t seg_len, uint32_t seg_stride, uint32_t n_queue, unsigned long long& tested) {
+__device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue,
+                                              uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr,
+                                              unsigned long long& tested) {
     const uint32_t lane = threadIdx.x & 63u;
-    // the wave's share of the queue: runs of seg_len entries starting at seg0, seg0 + seg_stride, ...
-    uint32_t next = seg0;  // wave-uniform cursor into the current run
-    uint32_t run0 = seg0;
-    uint32_t seg_end = (n_queue - seg0 < seg_len) ? n_queue : seg0 + seg_len;
+    // The queue is cut in runs of kSegment entries. Few runs: wave i traces run i. Many: the resident waves draw
+    // run after run from ONE ticket counter, in queue order - so the chip stays balanced to the end of the launch
+    // without the per-wave tails of long fixed segments, and the rays in flight at any moment are neighbours in the
+    // queue (= in the image), which is what keeps cells and objects in L2: drawing from 64 regions of the queue at
+    // once cost 62 ms per cfg4 frame, from one 46.5. Ticket demand (~26 per microsecond) is far below what one
+    // counter sustains (~88).
+    const uint32_t n_runs = (n_queue + kSegment - 1u) / kSegment;
+    const bool dynamic = n_runs > n_waves;
+    uint32_t next = 0, seg_end = 0;  // wave-uniform cursor into the current run
+    auto grab = [&]() -> bool {
+        uint32_t r = 0;
+        if (lane == 0u) r = atomicAdd(run_ctr, 1u);
+        r = __builtin_amdgcn_readfirstlane(r);
+        if (r >= n_runs) return false;
+        next = r * kSegment;
+        seg_end = (n_queue - next < kSegment) ? n_queue : next + kSegment;
+        return true;
+    };
+    bool more = dynamic;  // may another run be drawn?
+    if (dynamic) {
+        if (!grab()) return;
+    } else {
+        if (wave >= n_runs) return;
+        next = wave * kSegment;
+        seg_end = (n_queue - next < kSegment) ? n_queue : next + kSegment;
+    }
     const GridDesc& g = w.grid;
     const HotObject* __restrict__ hot = w.rp.scene.hot;
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -337,11 +360,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 }
             }
             next += (uint32_t)__popcll(idle);
-            if (next >= seg_end && (uint64_t)run0 + seg_stride < n_queue) {  // on to the wave's next run
-                run0 += seg_stride;
-                next = run0;
-                seg_end = (n_queue - run0 < seg_len) ? n_queue : run0 + seg_len;
-            }
+            if (next >= seg_end && more) more = grab();  // on to another run, if any is left
         }
         const unsigned long long live = __ballot(st != 0);
         if (live == 0ull) {
@@ -418,13 +437,12 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
 }
 
 template <bool FUSED, bool ANY>
-__global__ __launch_bounds__(256) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue) {
+__global__ __launch_bounds__(256) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue,
+                                                                 uint32_t* __restrict__ run_ctr) {
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * 256u) >> 6;
-    const uint64_t seg0 = (uint64_t)wave * kSegment;
-    if (seg0 >= n_queue) return;  // wave-uniform
     unsigned long long tested = 0;
-    trace_segment<FUSED, ANY>(w, queue, (uint32_t)seg0, kSegment, n_waves * kSegment, n_queue, tested);
+    trace_segment<FUSED, ANY>(w, queue, n_queue, wave, n_waves, run_ctr, tested);
     if (w.count_rays && tested) atomicAdd(&w.rp.counters->tests, tested);
 }
 
@@ -721,7 +739,7 @@ constexpr uint32_t kMaxSlices = 16;
 static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255u) / 256u)); }
 // one wave per kSegment queue entries, four waves per workgroup
 #ifndef RT_MAX_WAVES
-#define RT_MAX_WAVES 100000000
+#define RT_MAX_WAVES 8192  // 256 CUs x 4 SIMDs x 8: every wave that can be resident
 #endif
 static inline dim3 persistent_grid(uint64_t n) {
     uint64_t waves = (n + kSegment - 1) / kSegment;
@@ -763,12 +781,13 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
         w.n_prev_closest = nc;
         w.n_prev_any = na;
         const bool use_grid = w.grid.enabled && !w.rp.scene.literal;
+        if (use_grid && (e = hipMemsetAsync(buf.counts + 4, 0, 2 * sizeof(uint32_t), stream)) != hipSuccess) return e;
         if (nc) {
             if (use_grid && first && w.tiles.enabled && w.rp.pinhole) {
                 hipLaunchKernelGGL((wf_trace_primary_tiles<FUSED>), grid_for(nc), dim3(256), 0, stream, w, nc);
             } else if (use_grid) {
                 if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest_grid<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
-                else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, false>), persistent_grid(nc), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_closest, nc);
+                else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, false>), persistent_grid(nc), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_closest, nc, buf.counts + 4);
             } else {
                 if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
                 else hipLaunchKernelGGL((wf_trace_closest<FUSED, true>), grid_for(nc), dim3(256), 0, stream, w, nc);
@@ -780,7 +799,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
                 hipLaunchKernelGGL((wf_trace_any_literal<FUSED>), grid_for(na), dim3(256), 0, stream, w, na);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             } else if (use_grid) {
-                hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, true>), persistent_grid(na), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_any, na);
+                hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, true>), persistent_grid(na), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_any, na, buf.counts + 5);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             } else {
                 // slices of >= kMinSlicePairs pairs (amortises each launch's pipeline fill), at most kMaxSlices
