@@ -166,10 +166,14 @@ void repack_objects(const rt_object_data* objs, uint32_t n, std::vector<rt::HotP
 // sqrt(1 + ~1e-6 (|c|/R)^2) radii, (b) the fp32 rounding of the bundle test. Anything doubtful (singular or
 // non-finite matrices) gets +inf = never culled; unknown primitive types can never be hit = -inf.
 struct Sphere { double x, y, z, r; };
-Sphere make_sphere(double x, double y, double z, double r) { return Sphere{x, y, z, r}; }
-Sphere bounding_sphere(const rt_object_data& o) {
+// Bounding sphere of an instanced unit sphere / unit box in view space, in double precision and WITHOUT safety
+// margins (callers add the ones their use needs): centre -A^-1 b, radius r0 * sigma_max(A^-1) (r0 = 1 or
+// sqrt(0.75)), plus an upper bound of the squared condition number kappa^2 = (sigma_max / sigma_min)^2.
+// r = +inf: no usable bound (test it for every ray); r = -inf: unknown type, can never be hit.
+struct Bound { double x, y, z, r, kappa2; };
+Bound object_bound(const rt_object_data& o) {
     const double inf = std::numeric_limits<double>::infinity();
-#define make_float4 make_sphere
+#define make_float4(X, Y, Z, R) Bound{(double)(X), (double)(Y), (double)(Z), (double)(R), 1.0}
     if (o.type > 1u) return make_float4(0.f, 0.f, 0.f, -inf);
     const float* m = o.mvInverse;
     double A[3][3] = {{m[0], m[4], m[8]}, {m[1], m[5], m[9]}, {m[2], m[6], m[10]}};
@@ -226,11 +230,23 @@ Sphere bounding_sphere(const rt_object_data& o) {
     }
     const double r0 = (o.type == 0u) ? 1.0 : std::sqrt(0.75);
     const double R = r0 * std::sqrt(lam_max);
-    const double cl = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-    const double Reff = R * (1.0 + 1.0 / 512.0) + cl / 512.0;
-    if (!std::isfinite(Reff) || !std::isfinite(cl)) return make_float4(0.f, 0.f, 0.f, inf);
-    return make_float4(c[0], c[1], c[2], Reff);
+    // lambda_min >= det(S) / lambda_max^2 (the other two eigenvalues are <= lambda_max), det(S) = 1 / det(A)^2
+    const double kappa2 = lam_max * lam_max * lam_max * det * det * (1.0 + 1e-6);
+    if (!std::isfinite(R) || !std::isfinite(kappa2) || !(kappa2 >= 0.999) || !std::isfinite(c[0] + c[1] + c[2]))
+        return make_float4(0.f, 0.f, 0.f, inf);
+    Bound bd{c[0], c[1], c[2], R, kappa2 < 1.0 ? 1.0 : kappa2};
+    return bd;
 #undef make_float4
+}
+
+// the small-scene screen culling keeps its original, generous margins: 2^-9 of the radius and of the distance
+Sphere bounding_sphere(const rt_object_data& o) {
+    const Bound b = object_bound(o);
+    if (!std::isfinite(b.r)) return Sphere{0.0, 0.0, 0.0, b.r};
+    const double cl = std::sqrt(b.x * b.x + b.y * b.y + b.z * b.z);
+    const double Reff = b.r * (1.0 + 1.0 / 512.0) + cl / 512.0;
+    if (!std::isfinite(Reff)) return Sphere{0.0, 0.0, 0.0, std::numeric_limits<double>::infinity()};
+    return Sphere{b.x, b.y, b.z, Reff};
 }
 
 // Conservative projection of a bounding sphere onto the pinhole image plane, in ray-direction units
@@ -424,6 +440,13 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
         p.tile_rows = c->world > 1 ? (uint32_t)(c->tile_rays / c->width) : p.local_rows;
         if (p.tile_rows == 0) p.tile_rows = 1;
         p.n_bundles = p.bundles_x * ((p.local_rows + 7u) / 8u);
+        p.wf_tile_order = (c->width % 8u == 0 && p.local_rows % 8u == 0 && !std::getenv("RT_WF_ROW_ORDER")) ? 1u : 0u;
+        if (p.wf_tile_order) {
+            uint32_t shift = 0, cap = 5;
+            if (const char* env = std::getenv("RT_WF_SUPER_SHIFT")) cap = (uint32_t)std::atoi(env);
+            while (shift < cap && (c->width / 8u) % (2u << shift) == 0 && (p.local_rows / 8u) % (2u << shift) == 0) ++shift;
+            p.wf_super_shift = shift;
+        }
         p.tile_cull = (c->n_objs > 0 && c->n_objs <= 64 && c->z < 0.0f && !(c->flags & RT_FLAG_LITERAL)) ? 1u : 0u;
     } else {
         if (c->n_local > 0xffffffffull - 64) return fail(c, RT_ERR_INVALID_ARGUMENT, "too many rays for one launch");
@@ -535,24 +558,25 @@ int build_screen_tiles(rt_context* c, hipStream_t stream) {
 int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     c->grid = rt::GridDesc{};
     if (n == 0 || (c->flags & RT_FLAG_NO_GRID) || !c->affine_w || !c->primary_w_one) return RT_OK;
-    std::vector<Sphere> sph(n);
+    std::vector<Bound> sph(n);
     double lo[3] = {c->origin_lo[0], c->origin_lo[1], c->origin_lo[2]};
     double hi[3] = {c->origin_hi[0], c->origin_hi[1], c->origin_hi[2]};
     const double inf = std::numeric_limits<double>::infinity();
     for (uint32_t i = 0; i < n; ++i) {
-        sph[i] = bounding_sphere(objs[i]);  // r already carries the 2^-9 relative margins
+        sph[i] = object_bound(objs[i]);
         if (!std::isfinite(sph[i].r)) continue;  // +inf: always-list, -inf: can never be hit
         const double cc[3] = {sph[i].x, sph[i].y, sph[i].z};
+        const double pad = sph[i].r * 1.01;
         for (int a = 0; a < 3; ++a) {
-            lo[a] = std::min(lo[a], cc[a] - sph[i].r);
-            hi[a] = std::max(hi[a], cc[a] + sph[i].r);
+            lo[a] = std::min(lo[a], cc[a] - pad);
+            hi[a] = std::max(hi[a], cc[a] + pad);
         }
     }
     const double ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
     const double diag = std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
     if (!(diag > 0) || !std::isfinite(diag)) return RT_OK;
     // cell edge: about two cells per object in volume, at most 256 cells per axis
-    double cells_per_object = 4.0;
+    double cells_per_object = 2.0;
     if (const char* env = std::getenv("RT_GRID_CELLS_PER_OBJECT")) {  // tuning knob (results do not depend on it)
         const double v = std::atof(env);
         if (v > 0.01 && v < 1000.0) cells_per_object = v;
@@ -560,10 +584,26 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     double cell = std::cbrt(std::max(ext[0], 1e-6) * std::max(ext[1], 1e-6) * std::max(ext[2], 1e-6) / (cells_per_object * n));
     cell = std::max(cell, std::max(ext[0], std::max(ext[1], ext[2])) / 256.0);
     if (!(cell > 0) || !std::isfinite(cell)) return RT_OK;
-    // inflated radius per object: sqrt(R^2 + 1e-5 D^2) * 1.001 + 0.01 cell, D = reach of any ray origin
-    std::vector<double> rg(n);
+    // Radii (rt_grid.h derives the bound): with u = 2^-24, a ray that starts `dist` from the centre c of an object
+    // with bounding radius R and condition number kappa can only be accepted by the reference's fp32 test if its
+    // line passes c within
+    //     sqrt(R^2 (1 + 8u) + 14 u kappa^2 dist^2) + 10.4 u kappa (|start| + |c|) + 9 u kappa^2 dist.
+    // Everything below uses u_eff = 2e-7 (3.3 u):  a = R sqrt(1 + 2e-6),  L = 2.2e-6 kappa (S + |c|) + 2e-6 kappa^2 D,
+    //   registration radius  sqrt(a^2 + 3e-6 kappa^2 D^2) + L   (D = farthest possible ray origin, S = largest |origin|)
+    //   pre-test radius      a + 2L + 1e-6 |c|, used with the ACTUAL distance: r^2 = w^2 + alpha dist^2, alpha = 6e-6 K^2
+    // (K^2 = largest kappa^2 among the objects that use the distance-dependent form, at most 4; more anisotropic
+    // objects carry their full registration radius instead, flagged by a negative w).
+    double S_max = 0;
+    for (int k = 0; k < 8; ++k) {
+        const double px = (k & 1) ? hi[0] : lo[0], py = (k & 2) ? hi[1] : lo[1], pz = (k & 4) ? hi[2] : lo[2];
+        S_max = std::max(S_max, std::sqrt(px * px + py * py + pz * pz));
+    }
+    constexpr double kKappa2Tight = 4.0;
+    double K2 = 1.0;
+    std::vector<double> rg(n), rpre(n);
     std::vector<uint32_t> always;
     for (uint32_t i = 0; i < n; ++i) {
+        rpre[i] = 0;
         if (sph[i].r == -inf) { rg[i] = -1.0; continue; }
         if (!std::isfinite(sph[i].r)) { rg[i] = inf; always.push_back(i); continue; }
         double D2 = 0;
@@ -572,8 +612,15 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
             const double d = std::max(std::fabs(cc[a] - lo[a]), std::fabs(hi[a] - cc[a]));
             D2 += d * d;
         }
-        rg[i] = std::sqrt(sph[i].r * sph[i].r + 1e-5 * D2) * 1.001 + 0.01 * cell;
-        if (rg[i] > 0.25 * diag) { rg[i] = inf; always.push_back(i); }  // as big as the scene: test it for every ray
+        const double k2 = sph[i].kappa2, kap = std::sqrt(k2);
+        const double cl = std::sqrt(cc[0] * cc[0] + cc[1] * cc[1] + cc[2] * cc[2]);
+        const double a2 = sph[i].r * sph[i].r * (1.0 + 2e-6);
+        const double L = 2.2e-6 * kap * (S_max + cl) + 2e-6 * k2 * std::sqrt(D2);
+        const double reg = std::sqrt(a2 + 3e-6 * k2 * D2) + L;
+        rg[i] = reg * (1.0 + 1e-6) + 0.01 * cell;  // + slack for the kernels' fp32 cell arithmetic
+        if (k2 <= kKappa2Tight) { rpre[i] = std::sqrt(a2) + 2.0 * L + 1e-6 * cl; K2 = std::max(K2, k2); }
+        else rpre[i] = -(reg * (1.0 + 1e-6) + 1e-6 * cl);
+        if (!std::isfinite(rg[i]) || rg[i] > 0.25 * diag) { rg[i] = inf; always.push_back(i); }  // as big as the scene: test it for every ray
     }
     if (always.size() > 64) return RT_OK;  // a grid would not pay: stay with the brute-force stream
     // the grid box: everything registered plus the ray origins, padded by one cell
@@ -634,8 +681,9 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
                 std::vector<float4> es(total);
                 for (size_t k = 0; k < total; ++k) {
                     const uint32_t i = entries[k];
-                    const double cl = std::sqrt(sph[i].x * sph[i].x + sph[i].y * sph[i].y + sph[i].z * sph[i].z);
-                    const float r = std::nextafter((float)(rg[i] + 1e-6 * cl), std::numeric_limits<float>::infinity());
+                    // pre-test radius, rounded away from zero; negative = "already holds the worst-case distance term"
+                    const float r = rpre[i] >= 0 ? std::nextafter((float)rpre[i], std::numeric_limits<float>::infinity())
+                                                 : std::nextafter((float)rpre[i], -std::numeric_limits<float>::infinity());
                     es[k] = make_float4((float)sph[i].x, (float)sph[i].y, (float)sph[i].z, r);
                 }
                 RT_HIP(c, hipMalloc((void**)&c->d_grid_entry_sphere, sizeof(float4) * (total + 1)));
@@ -669,6 +717,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     g.entry_sphere = c->d_grid_entry_sphere;
     g.always = c->d_grid_always;
     g.n_always = (uint32_t)always.size();
+    g.pretest_alpha = std::nextafter((float)(6e-6 * K2 + 8e-6), std::numeric_limits<float>::infinity());
     g.enabled = 1u;
     c->h_grid_spheres.resize(4 * (size_t)n);
     for (uint32_t i = 0; i < n; ++i) {

@@ -3,21 +3,30 @@
 // The reference tests every ray against every object. The grid does not change WHAT is computed for an
 // object - a candidate still goes through the reference's exact test on the same object-space ray - it only
 // skips objects that cannot pass that test, so the result (winner index, t, visibility) is bit-identical to
-// the brute-force loops. "Cannot pass" has to hold for the reference's fp32 arithmetic, not for exact geometry:
-// its discriminant B^2 - 4AC carries an absolute error of up to ~40 eps * 4A|o|^2 (o = ray origin in object
-// space), so it can accept a ray whose line passes the unit sphere at b^2 <= 1 + ~2.4e-6 |o|^2. In view space
-// that is a sphere of radius sqrt(R^2 + 2.4e-6 D^2) for a ray that starts D away. The grid therefore registers
-// every object with
-//       R_grid = sqrt(R^2 + 1e-5 * D_k^2) * 1.001 + 0.01 cell
-// where R is the (double-precision, host-computed) radius of its bounding sphere and D_k the largest distance
-// from its centre to any possible ray origin (scene box, camera, uploaded ray origins) - a 4x margin on the
-// error bound - and the walk keeps going for two more cells after the current best hit. Objects whose bounds are
-// not finite or are as large as the scene sit in an "always" list that every ray tests. tests/ compare the grid
-// path with the brute-force path bit for bit (RT_FLAG_NO_GRID forces the latter).
+// the brute-force loops. "Cannot pass" has to hold for the reference's fp32 arithmetic, not for exact geometry.
+//
+// Bound (u = 2^-24; A, b = rows x,y,z of mvInverse; c = -A^-1 b the centre, R = r0 sigma_max(A^-1) the bounding
+// radius with r0 = 1 for the unit sphere and sqrt(0.75) for the unit box; kappa = cond(A); dist = |start - c|):
+//  * the object-space origin o^ = fl(A start + b) is off by |do| <= 6u |A|_F (|start| + |c|) (the sum cancels: the
+//    error scales with the coordinates, not with dist), the direction by a relative 5.2 u kappa;
+//  * on those computed vectors, radical = B^2 - 4AC differs from the exact 4A(1 - b*^2) (b* = distance of the
+//    computed line from the object's origin) by at most 4A u (14 |o^|^2 + 8), so `radical >= 0` needs
+//    b*^2 <= 1 + u (14 |o^|^2 + 8); the box's slab test accepts only if some point of the line has all three
+//    |p_i| <= 0.5 + 2u(|o^_i| + 0.5), which is inside the same expression with r0^2 in place of 1;
+//  * back in view space (|o^| <= kappa dist / sigma_max(A^-1), distances scale by at most sigma_max(A^-1)):
+//        the line passes c within  sqrt(R^2 (1 + 8u) + 14 u kappa^2 dist^2) + 10.4 u kappa (|start| + |c|) + 9 u kappa^2 dist.
+// build_grid (rt_api.cpp) evaluates this with u_eff = 2e-7 (3.3 u; also covers the unfused flavour's extra
+// roundings), in double precision, twice: with the farthest possible ray origin for the radius an object is
+// REGISTERED with (+ 0.01 cell for the walk's own fp32 arithmetic), and as a function of the ray's actual distance
+// for the PRE-TEST below. Objects whose bounds are not finite or as large as the scene sit in an "always" list that
+// every ray tests. A reported hit additionally needs t >= 0: the pre-test's "entirely behind" rejection keeps a
+// 1e-5 relative margin on |start - c|^2 - w^2, eight times what the cancellation in (root - B) / 2A can move.
+// tests/ compare the grid path with the brute-force path bit for bit (RT_FLAG_NO_GRID forces the latter).
 //
 // Order: cells are visited front to back and objects repeat across cells, so the closest-hit update uses the
 // order-free form of the reference's sequential tie rules (Q3): among the candidates with the smallest t the
-// winner is the highest-index sphere if there is one, else the lowest-index box.
+// winner is the highest-index sphere if there is one, else the lowest-index box. The walk keeps going for two
+// more cells after the current best hit.
 #pragma once
 
 #include "rt_device.h"
@@ -27,7 +36,10 @@ namespace rt {
 // One 64-byte record per cell: where its list starts, how long it is, and copies of the first three pre-test
 // spheres - for most cells everything a passing ray looks at, in ONE cache line (the separate offset / sphere /
 // index arrays cost three lines per visited cell, and the walk is bound by L1/L2 request traffic).
-constexpr uint32_t kCellInline = 3;
+#ifndef RT_CELL_INLINE
+#define RT_CELL_INLINE 3
+#endif
+constexpr uint32_t kCellInline = RT_CELL_INLINE;
 struct alignas(64) GridCell {
     uint32_t start;   // first entry of the cell in entries / entry_sphere
     uint32_t count;
@@ -46,6 +58,7 @@ struct GridDesc {
     const float4* __restrict__ entry_sphere;  // parallel to entries: the object's inflated bounding sphere (centre, R_grid)
     const uint32_t* __restrict__ always;      // objects every ray must test
     uint32_t n_always;
+    float pretest_alpha;   // distance-dependent term of the pre-test radius (misses_bounding_sphere)
     uint32_t enabled;
 };
 
@@ -74,17 +87,19 @@ __device__ __forceinline__ void closest_update_unordered(uint32_t type, float sx
     if (take) { T = t; index = k; cur_sphere = sphere; }
 }
 
-// Cheap conservative rejection of a grid candidate before its 52-byte matrix is fetched: does the ray's line
-// pass the object's INFLATED bounding sphere (the one the grid was built with, so all the reference's rounding is
-// already inside it), and is that sphere not entirely behind the ray origin? The test's own fp32 rounding
-// (~1e-6 |oc|^2 A on the discriminant) is covered by rejecting only below -8e-6 |oc|^2 A.
-__device__ __forceinline__ bool misses_bounding_sphere(const float4 s, const Ray& ray, float dd) {
+// Cheap conservative rejection of a grid candidate before its 52-byte matrix is fetched. s = (centre, w): the
+// reference's fp32 test can only accept a ray whose line passes the centre within sqrt(w^2 + 6e-6 K^2 |oc|^2)
+// (build_grid, rt_api.cpp: the bound is a function of the ray's ACTUAL distance |oc| from the object, which for
+// secondary rays is a small fraction of the scene size the cell registration has to assume). `alpha` adds 8e-6
+// for this test's own fp32 rounding (~1e-6 |oc|^2 A on the discriminant). A negative w marks an entry whose
+// radius already contains the worst-case distance term. Second test: the sphere is entirely behind the origin.
+__device__ __forceinline__ bool misses_bounding_sphere(const float4 s, const Ray& ray, float dd, float alpha) {
     const float ox = s.x - ray.sx, oy = s.y - ray.sy, oz = s.z - ray.sz;
     const float oo = ox * ox + oy * oy + oz * oz;
     const float od = ox * ray.dx + oy * ray.dy + oz * ray.dz;
     const float c = oo - s.w * s.w;
     const float disc = od * od - dd * c;
-    const float tol = 8.0e-6f * oo * dd;
+    const float tol = (s.w > 0.f ? alpha : 8.0e-6f) * oo * dd;
     if (disc < -tol) return true;                 // the line misses the sphere
     if (od < 0.f && c > 1.0e-5f * oo) return true;  // centre behind the origin and the origin clearly outside
     return false;                                 // (NaNs compare false: the candidate is tested)

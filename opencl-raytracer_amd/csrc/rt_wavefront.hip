@@ -51,6 +51,23 @@ struct WfParams {
     uint32_t count_rays;  // instrumentation on
 };
 
+// Work-item -> pixel of this rank's frame part. Pinhole frames are walked in 8x8-pixel tiles (work-items 64k ..
+// 64k+63 = one tile), so that the 64 rays a wave traces together, and the rays in flight on the chip, are
+// neighbours in the image in both directions; pixel state and queues are indexed by work-item, only the primary
+// ray and the final stores need the pixel.
+__device__ __forceinline__ uint64_t pixel_of(const RenderParams& p, uint64_t t) {
+    if (!p.wf_tile_order) return t;
+    const uint32_t tt = (uint32_t)t;
+    const uint32_t within = tt & 63u;
+    uint32_t tile = tt >> 6;
+    const uint32_t sh = p.wf_super_shift;  // blocks of 2^sh x 2^sh tiles, row-major inside and outside
+    const uint32_t block = tile >> (2u * sh), in_block = tile & ((1u << (2u * sh)) - 1u);
+    const uint32_t blocks_x = p.bundles_x >> sh;
+    const uint32_t brow = block / blocks_x, bcol = block - brow * blocks_x;
+    const uint32_t trow = (brow << sh) + (in_block >> sh), tcol = (bcol << sh) + (in_block & ((1u << sh) - 1u));
+    return (uint64_t)(((trow << 3) + (within >> 3)) * p.width + (tcol << 3) + (within & 7u));
+}
+
 __device__ __forceinline__ float& F(const WfParams& w, uint32_t f, uint64_t i) { return w.st[(uint64_t)f * w.rp.n_local + i]; }
 __device__ __forceinline__ uint32_t& U(const WfParams& w, uint32_t f, uint64_t i) {
     return reinterpret_cast<uint32_t*>(w.st)[(uint64_t)f * w.rp.n_local + i];
@@ -136,17 +153,18 @@ __global__ __launch_bounds__(kResumeThreads) void wf_begin(const WfParams w) {
 
 __device__ __forceinline__ bool begin_pixel(const WfParams& w, uint64_t i) {
     const RenderParams& p = w.rp;
-    uint64_t g = i;
+    const uint64_t px = pixel_of(p, i);
+    uint64_t g = px;
     if (p.world > 1u) {
-        const uint64_t tile = i / p.tile_rays;
-        const uint64_t off = i - tile * p.tile_rays;
+        const uint64_t tile = px / p.tile_rays;
+        const uint64_t off = px - tile * p.tile_rays;
         g = (tile * p.world + p.rank) * p.tile_rays + off;
     }
     if (g >= p.n_rays) {  // padding work-item of a ragged last tile
-        if (w.kernel == 0) reinterpret_cast<float*>(p.out)[i] = kMaxFloat;
-        else reinterpret_cast<float4*>(p.out)[i] = make_float4(0.f, 0.f, 0.f, 1.0f);
-        if (p.aux_t) p.aux_t[i] = kMaxFloat;
-        if (p.aux_index) p.aux_index[i] = -1;
+        if (w.kernel == 0) reinterpret_cast<float*>(p.out)[px] = kMaxFloat;
+        else reinterpret_cast<float4*>(p.out)[px] = make_float4(0.f, 0.f, 0.f, 1.0f);
+        if (p.aux_t) p.aux_t[px] = kMaxFloat;
+        if (p.aux_index) p.aux_index[px] = -1;
         U(w, F_PHASE, i) = PH_DONE;
         return false;
     }
@@ -216,10 +234,11 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams w, 
     const RenderParams& p = w.rp;
     const uint64_t i = w.q_prev_closest[t];
     const Ray ray = load_ray(w, i);
-    uint64_t g = i;
+    const uint64_t px = pixel_of(p, i);
+    uint64_t g = px;
     if (p.world > 1u) {
-        const uint64_t tile = i / p.tile_rays;
-        g = (tile * p.world + p.rank) * p.tile_rays + (i - tile * p.tile_rays);
+        const uint64_t tile = px / p.tile_rays;
+        g = (tile * p.world + p.rank) * p.tile_rays + (px - tile * p.tile_rays);
     }
     const uint32_t row = (uint32_t)g / p.width, col = (uint32_t)g - row * p.width;
     const uint32_t tile = (row >> 3) * w.tiles.tiles_x + (col >> 6);
@@ -387,7 +406,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         if (st == 2) {
             const float4* sp = (cj < kCellInline) ? &cellp->sphere[cj] : &g.entry_sphere[e];
             const float4 bound = *sp;
-            const bool pass = !misses_bounding_sphere(bound, ray, dd);
+            const bool pass = !misses_bounding_sphere(bound, ray, dd, g.pretest_alpha);
             if (pass && pend) {
                 blocked = true;  // one parking slot: wait for the exact tests
             } else {
@@ -436,8 +455,11 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
     }
 }
 
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 4
+#endif
 template <bool FUSED, bool ANY>
-__global__ __launch_bounds__(256) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU))) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue,
                                                                  uint32_t* __restrict__ run_ctr) {
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * 256u) >> 6;
@@ -501,7 +523,7 @@ struct Ctx {
 
 template <int KERNEL>
 __device__ __forceinline__ void write_pixel(Ctx& c, float r, float g, float b) {
-    reinterpret_cast<float4*>(c.w.rp.out)[c.i] = make_float4(r, g, b, 1.0f);
+    reinterpret_cast<float4*>(c.w.rp.out)[pixel_of(c.w.rp, c.i)] = make_float4(r, g, b, 1.0f);
     U(c.w, F_PHASE, c.i) = PH_DONE;
 }
 
@@ -687,10 +709,10 @@ __global__ __launch_bounds__(kResumeThreads) void wf_resume(const WfParams w) {
             const int idx = (int)U(w, F_RES_I, i);
             const bool hit = (KERNEL == 2) ? !(T == kMaxFloat) : (T < kMaxFloat);
             c.traced += 1; c.reference += 1; c.hits += hit ? 1 : 0;
-            if (w.rp.aux_t) w.rp.aux_t[i] = T;
-            if (w.rp.aux_index) w.rp.aux_index[i] = hit ? idx : -1;
+            if (w.rp.aux_t) w.rp.aux_t[pixel_of(w.rp, i)] = T;
+            if (w.rp.aux_index) w.rp.aux_index[pixel_of(w.rp, i)] = hit ? idx : -1;
             if (KERNEL == 0) {
-                reinterpret_cast<float*>(w.rp.out)[i] = hit ? T : kMaxFloat;
+                reinterpret_cast<float*>(w.rp.out)[pixel_of(w.rp, i)] = hit ? T : kMaxFloat;
                 U(w, F_PHASE, i) = PH_DONE;
             } else if (!hit) {
                 write_pixel<KERNEL>(c, 0.f, 0.f, 0.f);
