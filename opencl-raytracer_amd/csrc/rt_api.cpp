@@ -65,8 +65,7 @@ struct rt_context {
     int32_t* aux_index = nullptr;
 
     rt::GridDesc grid = {};                 // device pointers owned by this context
-    uint32_t* d_grid_cell_start = nullptr;
-    rt::GridCell* d_grid_cells = nullptr;
+    uint2* d_grid_cell_range = nullptr;
     uint32_t* d_grid_entries = nullptr;
     uint32_t* d_grid_always = nullptr;
     float4* d_grid_entry_sphere = nullptr;
@@ -83,7 +82,7 @@ struct rt_context {
     uint32_t last_rounds = 0;
 
     rt::Counters* d_counters = nullptr;
-    rt::Counters counters = {0, 0, 0, 0};
+    rt::Counters counters = {};
 
     hipEvent_t ev_begin[kTimingSlots];
     hipEvent_t ev_end[kTimingSlots];
@@ -400,7 +399,7 @@ int build_screen_tiles(rt_context* c, hipStream_t stream);
 
 int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     if (c->n_local == 0) {  // empty launch: nothing to render, nothing to time
-        if (count) c->counters = rt::Counters{0, 0, 0, 0};
+        if (count) c->counters = rt::Counters{};
         c->aux_t = nullptr;
         c->aux_index = nullptr;
         return RT_OK;
@@ -674,7 +673,6 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
             total = start[n_cells];
             if (total > 64ull * n + 1024) return RT_OK;  // objects too large for this cell size: not worth it
         } else {
-            RT_HIP(c, hipMalloc((void**)&c->d_grid_cell_start, sizeof(uint32_t) * (n_cells + 1)));
             RT_HIP(c, hipMalloc((void**)&c->d_grid_entries, sizeof(uint32_t) * (total + 1)));
             RT_HIP(c, hipMalloc((void**)&c->d_grid_always, sizeof(uint32_t) * (always.size() + 1)));
             {   // per entry: the sphere the object was registered with (rounded outwards), for the kernels' pre-test
@@ -688,19 +686,11 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
                 }
                 RT_HIP(c, hipMalloc((void**)&c->d_grid_entry_sphere, sizeof(float4) * (total + 1)));
                 if (total) RT_HIP(c, hipMemcpy(c->d_grid_entry_sphere, es.data(), sizeof(float4) * total, hipMemcpyHostToDevice));
-                std::vector<rt::GridCell> cells(n_cells);
-                for (size_t k = 0; k < n_cells; ++k) {
-                    rt::GridCell& gc = cells[k];
-                    gc.start = start[k];
-                    gc.count = start[k + 1] - start[k];
-                    gc.pad0 = gc.pad1 = 0;
-                    for (uint32_t j = 0; j < rt::kCellInline; ++j)
-                        gc.sphere[j] = j < gc.count ? es[start[k] + j] : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                RT_HIP(c, hipMalloc((void**)&c->d_grid_cells, sizeof(rt::GridCell) * n_cells));
-                RT_HIP(c, hipMemcpy(c->d_grid_cells, cells.data(), sizeof(rt::GridCell) * n_cells, hipMemcpyHostToDevice));
+                std::vector<uint2> ranges(n_cells);
+                for (size_t k = 0; k < n_cells; ++k) ranges[k] = make_uint2(start[k], start[k + 1] - start[k]);
+                RT_HIP(c, hipMalloc((void**)&c->d_grid_cell_range, sizeof(uint2) * n_cells));
+                RT_HIP(c, hipMemcpy(c->d_grid_cell_range, ranges.data(), sizeof(uint2) * n_cells, hipMemcpyHostToDevice));
             }
-            RT_HIP(c, hipMemcpy(c->d_grid_cell_start, start.data(), sizeof(uint32_t) * (n_cells + 1), hipMemcpyHostToDevice));
             if (total) RT_HIP(c, hipMemcpy(c->d_grid_entries, entries.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
             if (!always.empty())
                 RT_HIP(c, hipMemcpy(c->d_grid_always, always.data(), sizeof(uint32_t) * always.size(), hipMemcpyHostToDevice));
@@ -711,8 +701,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     g.cell = cellf;
     g.inv_cell = 1.0f / cellf;
     g.nx = dim[0]; g.ny = dim[1]; g.nz = dim[2];
-    g.cell_start = c->d_grid_cell_start;
-    g.cells = c->d_grid_cells;
+    g.cell_range = c->d_grid_cell_range;
     g.entries = c->d_grid_entries;
     g.entry_sphere = c->d_grid_entry_sphere;
     g.always = c->d_grid_always;
@@ -960,6 +949,17 @@ int rt_count_rays(rt_context* c) {
     if (c->n_local == 0) return RT_OK;
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipMemcpy(&c->counters, c->d_counters, sizeof(rt::Counters), hipMemcpyDeviceToHost));
+    if (std::getenv("RT_WALK_STATS")) {  // engineering aid: what the grid walk did in the counted frame
+        static const char* names[8] = {"rays", "wave trips", "live lane-trips", "cell fetches", "pre-tests", "exact tests", "exact rounds", "hand-out rounds"};
+        for (int k = 0; k < 2; ++k) {
+            const unsigned long long* v = c->counters.walk[k];
+            if (!v[0]) continue;
+            std::fprintf(stderr, "[walk %s]", k ? "any" : "closest");
+            for (int j = 0; j < 8; ++j) std::fprintf(stderr, " %s %llu", names[j], v[j]);
+            std::fprintf(stderr, " | per ray: fetches %.2f pre-tests %.2f exact %.2f lane-trips %.2f | live lanes/trip %.1f\n",
+                         (double)v[3] / v[0], (double)v[4] / v[0], (double)v[5] / v[0], (double)v[2] / v[0], (double)v[2] / (v[1] ? v[1] : 1));
+        }
+    }
     return RT_OK;
 }
 
@@ -1014,8 +1014,7 @@ void rt_destroy(rt_context* c) {
     if (c->d_hot) (void)hipFree(c->d_hot);
     if (c->d_cold) (void)hipFree(c->d_cold);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
-    if (c->d_grid_cell_start) (void)hipFree(c->d_grid_cell_start);
-    if (c->d_grid_cells) (void)hipFree(c->d_grid_cells);
+    if (c->d_grid_cell_range) (void)hipFree(c->d_grid_cell_range);
     if (c->d_grid_entries) (void)hipFree(c->d_grid_entries);
     if (c->d_grid_always) (void)hipFree(c->d_grid_always);
     if (c->d_grid_entry_sphere) (void)hipFree(c->d_grid_entry_sphere);

@@ -78,6 +78,9 @@ struct Counters {
     unsigned long long reference;  // rays the reference semantics trace
     unsigned long long hits;       // primary hits
     unsigned long long tests;      // ray-object tests executed by the wavefront traversal kernels (2 per pair visited)
+    // grid walk, counted pass only; [0] closest-hit rays, [1] shadow rays:
+    // rays, wave trips, live lane-trips, cell fetches, pre-tests, exact tests, exact-test rounds, hand-out rounds
+    unsigned long long walk[2][8];
 };
 
 // ---- arithmetic primitives -----------------------------------------------------------------------------

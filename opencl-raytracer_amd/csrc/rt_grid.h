@@ -33,27 +33,12 @@
 
 namespace rt {
 
-// One 64-byte record per cell: where its list starts, how long it is, and copies of the first three pre-test
-// spheres - for most cells everything a passing ray looks at, in ONE cache line (the separate offset / sphere /
-// index arrays cost three lines per visited cell, and the walk is bound by L1/L2 request traffic).
-#ifndef RT_CELL_INLINE
-#define RT_CELL_INLINE 3
-#endif
-constexpr uint32_t kCellInline = RT_CELL_INLINE;
-struct alignas(64) GridCell {
-    uint32_t start;   // first entry of the cell in entries / entry_sphere
-    uint32_t count;
-    uint32_t pad0, pad1;
-    float4 sphere[kCellInline];  // = entry_sphere[start .. start + 2]
-};
-
 struct GridDesc {
     float lox, loy, loz;        // grid origin (view space)
     float inv_cell;             // 1 / cell edge
     float cell;                 // cell edge
     int nx, ny, nz;
-    const uint32_t* __restrict__ cell_start;  // nx*ny*nz + 1 offsets into entries
-    const GridCell* __restrict__ cells;       // nx*ny*nz records (the persistent walk reads these instead of cell_start)
+    const uint2* __restrict__ cell_range;     // nx*ny*nz x {first entry, number of entries}
     const uint32_t* __restrict__ entries;     // object indices, ascending inside a cell
     const float4* __restrict__ entry_sphere;  // parallel to entries: the object's inflated bounding sphere (centre, R_grid)
     const uint32_t* __restrict__ always;      // objects every ray must test
@@ -209,6 +194,45 @@ __device__ __forceinline__ bool walk_next(const GridDesc& g, Walk& w) {
     }
 }
 
+// The same walk in the form the persistent kernel carries per lane: a running cell index and per-axis step
+// budgets instead of three coordinates, and a branch-free step (same axis choice, ties x before y before z, so the
+// cells and their order are those of walk_next).
+struct LeanWalk {
+    int c;                 // current cell (linear index)
+    int rx, ry, rz;        // steps left along each axis before the walk leaves the grid
+    int sx, sy, sz;        // index stride of one step along each axis (+-1, +-nx, +-nx*ny)
+    float tx, ty, tz, dtx, dty, dtz, t_enter;
+};
+
+__device__ __forceinline__ LeanWalk lean_walk(const GridDesc& g, const Walk& w) {
+    LeanWalk k;
+    k.c = (w.iz * g.ny + w.iy) * g.nx + w.ix;
+    k.rx = w.stepx > 0 ? g.nx - 1 - w.ix : w.ix;
+    k.ry = w.stepy > 0 ? g.ny - 1 - w.iy : w.iy;
+    k.rz = w.stepz > 0 ? g.nz - 1 - w.iz : w.iz;
+    k.sx = w.stepx; k.sy = w.stepy * g.nx; k.sz = w.stepz * g.nx * g.ny;
+    k.tx = w.tx; k.ty = w.ty; k.tz = w.tz; k.dtx = w.dtx; k.dty = w.dty; k.dtz = w.dtz;
+    k.t_enter = w.t_enter;
+    return k;
+}
+
+__device__ __forceinline__ bool lean_next(LeanWalk& k) {
+    const float tmin = __builtin_fminf(__builtin_fminf(k.tx, k.ty), k.tz);
+    const bool ax = (k.tx <= k.ty) && (k.tx <= k.tz);
+    const bool ay = !ax && (k.ty <= k.tz);
+    const bool az = !ax && !ay;
+    k.t_enter = ax ? k.tx : (ay ? k.ty : k.tz);
+    (void)tmin;
+    k.tx = ax ? k.tx + k.dtx : k.tx;
+    k.ty = ay ? k.ty + k.dty : k.ty;
+    k.tz = az ? k.tz + k.dtz : k.tz;
+    k.c += ax ? k.sx : (ay ? k.sy : k.sz);
+    k.rx -= ax ? 1 : 0;
+    k.ry -= ay ? 1 : 0;
+    k.rz -= az ? 1 : 0;
+    return (k.rx | k.ry | k.rz) >= 0;
+}
+
 // Closest hit through the grid. Same (T, index) as closest_hit() over all objects.
 template <bool FUSED, bool DW0>
 __device__ __forceinline__ void closest_hit_grid(const GridDesc& g, const HotObject* __restrict__ hot, const Ray& ray, float& T,
@@ -230,7 +254,8 @@ __device__ __forceinline__ void closest_hit_grid(const GridDesc& g, const HotObj
     const float slack = len > 0.f ? 2.0f * g.cell / len : 3.0e38f;
     for (;;) {
         const uint32_t c = ((uint32_t)w.iz * (uint32_t)g.ny + (uint32_t)w.iy) * (uint32_t)g.nx + (uint32_t)w.ix;
-        const uint32_t e0 = g.cell_start[c], e1 = g.cell_start[c + 1];
+        const uint2 range = g.cell_range[c];
+        const uint32_t e0 = range.x, e1 = range.x + range.y;
         tested += e1 - e0;
         for (uint32_t e = e0; e < e1; ++e) {
             const int k = (int)g.entries[e];

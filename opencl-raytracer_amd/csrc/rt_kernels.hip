@@ -41,7 +41,7 @@ __device__ __forceinline__ uint64_t bundle_candidates(const float4* __restrict__
 // saturates that counter at ~88 tickets/us (3 ms for a 4096^2 frame).
 template <int KERNEL, bool FUSED, bool COUNT>
 __global__ __launch_bounds__(256) void render_pixels(const RenderParams p) {
-    Counters ctr = {0ull, 0ull, 0ull, 0ull};
+    Counters ctr = {};
     const uint32_t lane = threadIdx.x & 63u;
     const Scene& S = p.scene;
     {

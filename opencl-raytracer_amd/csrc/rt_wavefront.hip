@@ -282,12 +282,12 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams w, 
 // / pre-test / full test - so that the full test only runs with half the wave ready: 2x SLOWER, the extra trips
 // and ballots cost more than the better packing of the expensive phase saves.)
 #ifndef RT_SEGMENT
-#define RT_SEGMENT 64  // queue entries per run
+#define RT_SEGMENT 128  // queue entries per run (64: 33.8 ms per cfg4 frame, 128: 32.2)
 #endif
 constexpr uint32_t kSegment = RT_SEGMENT;
 
 #ifndef RT_REFILL_MIN
-#define RT_REFILL_MIN 8  // new rays are handed out once this many lanes are idle (setting a ray up is ~150 instructions)
+#define RT_REFILL_MIN 16  // new rays are handed out once this many lanes are idle (setting a ray up is ~150 instructions)
 #endif
 #ifndef RT_DEFER_PENDING
 #define RT_DEFER_PENDING 16  // run the exact tests once this many lanes hold a candidate ...
@@ -301,7 +301,7 @@ constexpr uint32_t kSegment = RT_SEGMENT;
 // instructions - runs for the whole wave when enough lanes hold one (or are stuck behind theirs), so it executes
 // with tens of lanes instead of the 3-5 that happen to need it in any single trip. The closest-hit update is
 // order-free and T only ever shrinks, so a late update can only make a lane look at MORE cells than necessary.
-template <bool FUSED, bool ANY>
+template <bool FUSED, bool ANY, bool STATS>
 __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue,
                                               uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr,
                                               unsigned long long& tested) {
@@ -336,13 +336,12 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
     const HotObject* __restrict__ hot = w.rp.scene.hot;
     const unsigned long long below = (1ull << lane) - 1ull;
 
+    unsigned long long s_rays = 0, s_trips = 0, s_live = 0, s_fetch = 0, s_pre = 0, s_flush = 0, s_refill = 0;  // STATS only
     int st = 0;            // 0 idle (needs a ray), 1 at a cell whose list has not been fetched, 2 walking a list, 3 walk over
     uint32_t pix = 0;      // pixel whose ray this lane is tracing
     Ray ray = {};
-    Walk wk = {};
+    LeanWalk wk = {};
     uint32_t e = 0, e1 = 0;      // the current cell's list: next entry, end
-    uint32_t cj = 0;             // ... and where the next entry's sphere sits inside the cell record (>= kCellInline: not)
-    const GridCell* cellp = nullptr;
     float T = kMaxFloat, slack = 0.f, dd = 0.f;
     int idx = -1;
     bool cur_sphere = false;
@@ -354,7 +353,9 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         const unsigned long long idle = __ballot(st == 0);
         if (next < seg_end && ((uint32_t)__popcll(idle) >= (uint32_t)RT_REFILL_MIN || idle == ~0ull)) {
             const uint32_t mine = next + (uint32_t)__popcll(idle & below);
+            if (STATS && lane == 0u) ++s_refill;
             if (st == 0 && mine < seg_end) {
+                if (STATS) ++s_rays;
                 pix = queue[mine];
                 ray = load_ray(w, pix);
                 T = kMaxFloat; idx = -1; cur_sphere = false; pend = false;
@@ -370,8 +371,10 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 }
                 dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
                 slack = dd > 0.f ? 2.0f * g.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
-                if (!done) wk = walk_begin(g, ray, ANY ? 1.0f + slack : 3.0e38f);
-                if (done || !wk.alive) {  // occluded by an always-object, or the ray misses the grid box
+                Walk w0 = {};
+                if (!done) w0 = walk_begin(g, ray, ANY ? 1.0f + slack : 3.0e38f);
+                wk = lean_walk(g, w0);
+                if (done || !w0.alive) {  // occluded by an always-object, or the ray misses the grid box
                     if (ANY) U(w, F_RES_I, pix) = done ? 0u : 1u;
                     else { F(w, F_RES_T, pix) = T; U(w, F_RES_I, pix) = (uint32_t)idx; }
                 } else {
@@ -387,40 +390,30 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             continue;
         }
         bool advance = false, blocked = false;
+        if (STATS) { if (lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); } if (st == 1) ++s_fetch; if (st == 2) ++s_pre; }
         // ---- phase A: fetch the current cell's list ----
         if (st == 1) {
-            const uint32_t c = ((uint32_t)wk.iz * (uint32_t)g.ny + (uint32_t)wk.iy) * (uint32_t)g.nx + (uint32_t)wk.ix;
-            cellp = g.cells + c;
-            const uint2 hdr = *reinterpret_cast<const uint2*>(cellp);
-            e = hdr.x;
-            e1 = hdr.x + hdr.y;
-            cj = 0;
-#ifdef RT_CELL_LAZY
-            if (e < e1) st = 4;   // first candidate next trip (its line is on the way)
-#else
+            const uint2 range = g.cell_range[wk.c];
+            e = range.x;
+            e1 = range.x + range.y;
             if (e < e1) st = 2;
-#endif
             else advance = true;
         }
         // ---- phase B: pre-test one candidate (also for a lane that has just fetched a non-empty cell) ----
         if (st == 2) {
-            const float4* sp = (cj < kCellInline) ? &cellp->sphere[cj] : &g.entry_sphere[e];
-            const float4 bound = *sp;
+            const float4 bound = g.entry_sphere[e];
             const bool pass = !misses_bounding_sphere(bound, ray, dd, g.pretest_alpha);
             if (pass && pend) {
                 blocked = true;  // one parking slot: wait for the exact tests
             } else {
                 if (pass) { pend = true; pend_e = e; }
-                ++e; ++cj;
+                ++e;
                 if (e == e1) advance = true;
             }
         }
-#ifdef RT_CELL_LAZY
-        if (st == 4) st = 2;
-#endif
         // ---- step to the next cell, or end the walk ----
         if (advance) {
-            const bool inside = walk_next(g, wk);
+            const bool inside = lean_next(wk);
             const float limit = ANY ? 1.0f + slack : T + slack;
             st = (!inside || wk.t_enter > limit) ? 3 : 1;
         }
@@ -431,6 +424,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             const uint32_t n_live = (uint32_t)__popcll(live);
             if ((uint32_t)__popcll(pending) >= (uint32_t)RT_DEFER_PENDING ||
                 ((uint32_t)__popcll(stuck) << RT_DEFER_STUCK_SHIFT) >= n_live) {
+                if (STATS && lane == 0u) ++s_flush;
                 if (pend) {
                     float sx, sy, sz, dx, dy, dz;
                     uint32_t type;
@@ -453,19 +447,23 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             st = 0;
         }
     }
+    if (STATS) {
+        unsigned long long* acc = w.rp.counters->walk[ANY ? 1 : 0];
+        const unsigned long long v[8] = {wave_sum64(s_rays), s_trips, s_live, wave_sum64(s_fetch), wave_sum64(s_pre), wave_sum64(tested), s_flush, s_refill};
+        if (lane == 0u)
+            for (int j = 0; j < 8; ++j)
+                if (v[j]) atomicAdd(&acc[j], v[j]);
+    }
 }
 
-#ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 4
-#endif
-template <bool FUSED, bool ANY>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU))) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue,
+template <bool FUSED, bool ANY, bool STATS>
+__global__ __launch_bounds__(256) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue,
                                                                  uint32_t* __restrict__ run_ctr) {
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * 256u) >> 6;
     unsigned long long tested = 0;
-    trace_segment<FUSED, ANY>(w, queue, n_queue, wave, n_waves, run_ctr, tested);
-    if (w.count_rays && tested) atomicAdd(&w.rp.counters->tests, tested);
+    trace_segment<FUSED, ANY, STATS>(w, queue, n_queue, wave, n_waves, run_ctr, tested);
+    if (STATS && tested) atomicAdd(&w.rp.counters->tests, tested);
 }
 
 // Literal shadow test: the reference's full closest hit, then its `time >= 1 || time < 0` (:229).
@@ -809,7 +807,8 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
                 hipLaunchKernelGGL((wf_trace_primary_tiles<FUSED>), grid_for(nc), dim3(256), 0, stream, w, nc);
             } else if (use_grid) {
                 if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest_grid<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
-                else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, false>), persistent_grid(nc), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_closest, nc, buf.counts + 4);
+                else if (w.count_rays) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, false, true>), persistent_grid(nc), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_closest, nc, buf.counts + 4);
+                else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, false, false>), persistent_grid(nc), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_closest, nc, buf.counts + 4);
             } else {
                 if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
                 else hipLaunchKernelGGL((wf_trace_closest<FUSED, true>), grid_for(nc), dim3(256), 0, stream, w, nc);
@@ -821,7 +820,8 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
                 hipLaunchKernelGGL((wf_trace_any_literal<FUSED>), grid_for(na), dim3(256), 0, stream, w, na);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             } else if (use_grid) {
-                hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, true>), persistent_grid(na), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_any, na, buf.counts + 5);
+                if (w.count_rays) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, true, true>), persistent_grid(na), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_any, na, buf.counts + 5);
+                else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, true, false>), persistent_grid(na), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_any, na, buf.counts + 5);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             } else {
                 // slices of >= kMinSlicePairs pairs (amortises each launch's pipeline fill), at most kMaxSlices
