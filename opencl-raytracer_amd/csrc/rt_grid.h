@@ -217,16 +217,17 @@ __device__ __forceinline__ LeanWalk lean_walk(const GridDesc& g, const Walk& w) 
 }
 
 __device__ __forceinline__ bool lean_next(LeanWalk& k) {
+    // written with plain selects of 0 / value so that the fields stay in registers (an indexed pick of
+    // tx/ty/tz or sx/sy/sz makes the compiler move the struct to LDS)
     const float tmin = __builtin_fminf(__builtin_fminf(k.tx, k.ty), k.tz);
     const bool ax = (k.tx <= k.ty) && (k.tx <= k.tz);
     const bool ay = !ax && (k.ty <= k.tz);
     const bool az = !ax && !ay;
-    k.t_enter = ax ? k.tx : (ay ? k.ty : k.tz);
-    (void)tmin;
-    k.tx = ax ? k.tx + k.dtx : k.tx;
-    k.ty = ay ? k.ty + k.dty : k.ty;
-    k.tz = az ? k.tz + k.dtz : k.tz;
-    k.c += ax ? k.sx : (ay ? k.sy : k.sz);
+    k.t_enter = tmin;
+    k.tx += ax ? k.dtx : 0.f;
+    k.ty += ay ? k.dty : 0.f;
+    k.tz += az ? k.dtz : 0.f;
+    k.c += (ax ? k.sx : 0) + (ay ? k.sy : 0) + (az ? k.sz : 0);
     k.rx -= ax ? 1 : 0;
     k.ry -= ay ? 1 : 0;
     k.rz -= az ? 1 : 0;

@@ -358,6 +358,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 if (STATS) ++s_rays;
                 pix = queue[mine];
                 ray = load_ray(w, pix);
+                ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
                 T = kMaxFloat; idx = -1; cur_sphere = false; pend = false;
                 bool done = false;
                 for (uint32_t a = 0; a < g.n_always && !done; ++a) {  // objects every ray must test (usually none)
@@ -365,7 +366,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                     float sx, sy, sz, dx, dy, dz;
                     uint32_t type;
                     lane_object_space<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
-                    ++tested;
+                    if (STATS) ++tested;
                     if (ANY) done = occludes<FUSED>(type, sx, sy, sz, dx, dy, dz);
                     else closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, k, T, idx, cur_sphere);
                 }
@@ -430,7 +431,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                     uint32_t type;
                     const int pend_k = (int)g.entries[pend_e];
                     lane_object_space<FUSED, true>(hot + pend_k, ray, sx, sy, sz, dx, dy, dz, type);
-                    ++tested;
+                    if (STATS) ++tested;
                     pend = false;
                     if (ANY) {
                         if (occludes<FUSED>(type, sx, sy, sz, dx, dy, dz)) { U(w, F_RES_I, pix) = 0u; st = 0; }
@@ -456,8 +457,11 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
     }
 }
 
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 6
+#endif
 template <bool FUSED, bool ANY, bool STATS>
-__global__ __launch_bounds__(256) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU))) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue,
                                                                  uint32_t* __restrict__ run_ctr) {
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * 256u) >> 6;
