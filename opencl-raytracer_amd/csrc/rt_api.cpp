@@ -439,13 +439,7 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
         p.tile_rows = c->world > 1 ? (uint32_t)(c->tile_rays / c->width) : p.local_rows;
         if (p.tile_rows == 0) p.tile_rows = 1;
         p.n_bundles = p.bundles_x * ((p.local_rows + 7u) / 8u);
-        p.wf_tile_order = (c->width % 8u == 0 && p.local_rows % 8u == 0 && !std::getenv("RT_WF_ROW_ORDER")) ? 1u : 0u;
-        if (p.wf_tile_order) {
-            uint32_t shift = 0, cap = 5;
-            if (const char* env = std::getenv("RT_WF_SUPER_SHIFT")) cap = (uint32_t)std::atoi(env);
-            while (shift < cap && (c->width / 8u) % (2u << shift) == 0 && (p.local_rows / 8u) % (2u << shift) == 0) ++shift;
-            p.wf_super_shift = shift;
-        }
+        p.wf_tile_order = (c->width % 8u == 0 && p.local_rows % 8u == 0) ? 1u : 0u;
         p.tile_cull = (c->n_objs > 0 && c->n_objs <= 64 && c->z < 0.0f && !(c->flags & RT_FLAG_LITERAL)) ? 1u : 0u;
     } else {
         if (c->n_local > 0xffffffffull - 64) return fail(c, RT_ERR_INVALID_ARGUMENT, "too many rays for one launch");

@@ -18,7 +18,6 @@ struct RenderParams {
     float half_w, half_h, height_f, z;
     uint32_t dir_w_zero;              // every primary direction has w == 0 exactly
     uint32_t wf_tile_order;           // wavefront path: work-item t is pixel (8x8 tile t/64, position t%64) instead of pixel t
-    uint32_t wf_super_shift;          // ... and tiles are walked in square blocks of 2^shift x 2^shift tiles
     uint32_t tile2d;                  // pinhole + row-tile shards: one 8x8-pixel bundle per wave iteration
     uint32_t tile_cull;               // per-bundle screen-rectangle test of every object (scene.bounds holds rectangles)
     uint32_t bundles_x;               // 8-pixel bundle columns per bundle row

@@ -58,13 +58,8 @@ struct WfParams {
 __device__ __forceinline__ uint64_t pixel_of(const RenderParams& p, uint64_t t) {
     if (!p.wf_tile_order) return t;
     const uint32_t tt = (uint32_t)t;
-    const uint32_t within = tt & 63u;
-    uint32_t tile = tt >> 6;
-    const uint32_t sh = p.wf_super_shift;  // blocks of 2^sh x 2^sh tiles, row-major inside and outside
-    const uint32_t block = tile >> (2u * sh), in_block = tile & ((1u << (2u * sh)) - 1u);
-    const uint32_t blocks_x = p.bundles_x >> sh;
-    const uint32_t brow = block / blocks_x, bcol = block - brow * blocks_x;
-    const uint32_t trow = (brow << sh) + (in_block >> sh), tcol = (bcol << sh) + (in_block & ((1u << sh) - 1u));
+    const uint32_t tile = tt >> 6, within = tt & 63u;
+    const uint32_t trow = tile / p.bundles_x, tcol = tile - trow * p.bundles_x;
     return (uint64_t)(((trow << 3) + (within >> 3)) * p.width + (tcol << 3) + (within & 7u));
 }
 

@@ -342,6 +342,82 @@ def test_grid_tiny_far_objects_numerical_fuzz():
     assert int(np.any(out[:, :3] != 0, axis=1).sum()) > 50
 
 
+def _instanced(rng, n, scales, zrange, spread, box_every=3):
+    from helpers import instance
+    recs = []
+    for i in range(n):
+        pos = (rng.uniform(-spread, spread), rng.uniform(-spread, spread), rng.uniform(*zrange))
+        rot = rotation(rng.normal(size=3), rng.uniform(0, 2 * np.pi))
+        mv, inv = instance(pos, rot, scales(rng))
+        mat = R.Material((rng.uniform(), rng.uniform(), rng.uniform()), (.5, .5, .5), (.5, .5, .5),
+                         absorption=float(rng.choice([0.3, 0.6, 1.0])), shininess=float(rng.uniform(1, 30)))
+        recs.append(R.make_object(R.BOX if box_every and i % box_every == 0 else R.SPHERE, mat, mv, inv))
+    return R.objects_array(recs)
+
+
+def test_grid_strongly_anisotropic_objects():
+    """Needles and pancakes (axis ratios up to 150, rotated): the condition number enters the grid's error bound
+    squared, objects with kappa^2 > 4 carry their full registration radius in the pre-test (negative w), the
+    rest use the distance-dependent form - both must keep every hit the reference's fp32 test reports."""
+    rng = np.random.default_rng(777)
+    def scales(rng):
+        kind = rng.integers(0, 4)
+        if kind == 0: return (rng.uniform(0.01, 0.03), rng.uniform(1.0, 3.0), rng.uniform(0.2, 0.5))   # needle-ish plate
+        if kind == 1: return (rng.uniform(0.5, 1.5), rng.uniform(0.5, 1.5), rng.uniform(0.01, 0.02))    # pancake
+        if kind == 2: return (rng.uniform(0.3, 0.5),) * 3                                             # isotropic
+        return (rng.uniform(0.2, 0.4), rng.uniform(0.4, 0.8), rng.uniform(0.3, 0.5))                   # mild (kappa^2 <= 4)
+    objs = _instanced(rng, 1500, scales, (-70.0, -15.0), 18.0)
+    lights = R.lights_array([R.make_light(R.LightProperties((.2, .2, .2), (.6, .6, .6), (.8, .8, .8)), position=(15, 20, 5, 1)),
+                             R.make_light(R.LightProperties((.1, .1, .1), (.4, .4, .4), (.5, .5, .5)), position=(-25, -5, -40, 1))])
+    rays = camera.primary_rays(128, 96)
+    out = _grid_equals_brute(objs, lights, rays, 3, kernels=("hittest", "shade_and_reflect"))
+    assert int(np.any(out[:, :3] != 0, axis=1).sum()) > 2000
+
+
+def test_grid_grazing_rays():
+    """Rays aimed at the silhouettes of spheres from far away, offset from the tangent by -4..+4 parts per million
+    of the radius - the rays the reference's discriminant decides by rounding. Nearest t and index must be
+    those of the brute-force loop for every one of them."""
+    rng = np.random.default_rng(2718)
+    objs = _instanced(rng, 600, lambda r: (r.choice([0.05, 0.2, 0.5]),) * 3, (-110.0, -20.0), 30.0, box_every=0)
+    centres = objs["mv"].reshape(-1, 4, 4)[:, 3, :3].astype(np.float64)       # column-major: translation = column 3
+    radii = np.linalg.norm(objs["mv"].reshape(-1, 4, 4)[:, 0, :3].astype(np.float64), axis=1)
+    rays = np.zeros(600 * 64, dtype=R.RAY_DTYPE)
+    k = 0
+    for i in range(600):
+        for j in range(64):
+            origin = np.array([rng.uniform(-30, 30), rng.uniform(-30, 30), rng.uniform(-5, 5)]) if j % 2 else np.zeros(3)
+            to_c = centres[i] - origin
+            dist = np.linalg.norm(to_c)
+            side = np.cross(to_c, rng.normal(size=3)); side /= np.linalg.norm(side)
+            off = radii[i] * (1.0 + rng.integers(-4, 5) * 1e-6)
+            # tangent point of a cone around to_c: the line passes the centre at distance `off`
+            sin_a = off / dist
+            d = to_c / dist * np.sqrt(max(1.0 - sin_a * sin_a, 0.0)) + side * sin_a
+            rays["start"][k] = (*origin, 1.0)
+            rays["direction"][k] = (*(d * rng.uniform(0.5, 300.0)), 0.0)
+            k += 1
+    lights = R.lights_array([R.make_light(R.LightProperties((.2, .2, .2), (.6, .6, .6), (.8, .8, .8)), position=(0, 30, 0, 1))])
+    with hip(objs, lights, rays, 1, kernel="hittest", path="wavefront", grid=True) as rt:
+        a = rt.Render()
+    with hip(objs, lights, rays, 1, kernel="hittest", path="wavefront", grid=False) as rt:
+        b = rt.Render()
+    assert same_floats(a, b)
+    hits = int((a < 3.0e38).sum())
+    assert 0.2 * len(rays) < hits < len(rays)      # a healthy mix of both outcomes
+    _grid_equals_brute(objs, lights, rays[: 600 * 16], 2)
+
+
+def test_grid_ticketed_runs_on_a_long_queue():
+    """More rays than the resident waves can take one run each (> 8192 x 128): the persistent waves draw runs from
+    the ticket counter. Same frame as the brute-force path, bit for bit."""
+    from opencl_raytracer_amd import synthetic
+    objs, lights = synthetic.spheres_and_lights(1500, 3, absorption=0.5, seed=99)
+    rays = camera.crop_rays(4096, 4096, 1400, 1500, 1280, 1024)   # 1 310 720 rays
+    assert len(rays) > 8192 * 128
+    _grid_equals_brute(objs, lights, rays, 2)
+
+
 def test_grid_rays_starting_inside_objects_and_lights_inside_the_cloud():
     objs, lights = random_scene(700, 300, 3, seed=1234, spread=5.0, zrange=(-14.0, 4.0))  # the camera sits inside the cloud
     lights["position"][0] = (0.5, -0.5, -6.0, 1.0)                                          # a light in the middle of it
