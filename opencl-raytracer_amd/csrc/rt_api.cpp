@@ -346,6 +346,10 @@ bool use_wavefront(const rt_context* c) {
 
 void free_wavefront(rt_context* c) {
     rt::WavefrontBuffers& b = c->wf;
+    if (b.side_stream) (void)hipStreamDestroy(b.side_stream);
+    if (b.ev_fork) (void)hipEventDestroy(b.ev_fork);
+    if (b.ev_join) (void)hipEventDestroy(b.ev_join);
+    b.side_stream = nullptr; b.ev_fork = b.ev_join = nullptr;
     if (b.state) (void)hipFree(b.state);
     for (int i = 0; i < 2; ++i) {
         if (b.q_closest[i]) (void)hipFree(b.q_closest[i]);
@@ -389,6 +393,9 @@ int ensure_wavefront(rt_context* c) {
     }
     RT_HIP(c, hipMalloc((void**)&b.counts, 8 * sizeof(uint32_t)));  // 4 queue counters + 2 run-ticket counters
     RT_HIP(c, hipHostMalloc((void**)&b.h_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    RT_HIP(c, hipStreamCreateWithFlags(&b.side_stream, hipStreamNonBlocking));
+    RT_HIP(c, hipEventCreateWithFlags(&b.ev_fork, hipEventDisableTiming));
+    RT_HIP(c, hipEventCreateWithFlags(&b.ev_join, hipEventDisableTiming));
     b.shadow_pairs = c->d_shadow_pairs;
     b.grid = c->grid;
     b.capacity = n;

@@ -45,6 +45,8 @@ struct WavefrontBuffers {
     uint32_t* counts = nullptr;                    // 4 queue counters + 2 run-ticket counters of the grid walk
     uint32_t* h_counts = nullptr;                  // 4 x uint32 pinned host mirror
     uint64_t capacity = 0;                         // n_local the buffers were sized for
+    hipStream_t side_stream = nullptr;             // a round's shadow-ray launch runs here, next to the closest-hit launch
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 size_t wavefront_state_bytes(uint64_t n_local);
 size_t wavefront_queue_bytes(uint64_t n_local);

@@ -10,21 +10,26 @@
 //   wf_resume   : consumes each pixel's trace result, advances its state machine to the next ray it needs
 //                 (shadow ray of the next light in the scan, or the next reflection ray) or writes the pixel
 //
-// A pixel has at most one ray in flight, so a frame takes (rays on the longest pixel) rounds - about 2+2D.
-// State traffic per round (~0.4 KB/pixel) is noise next to N x 35 VALU instructions per ray. The arithmetic
+// A pixel has one closest-hit ray and/or one shadow ray in flight: in shade_and_reflect the reflection ray that
+// leaves a hit is queued together with the hit's first shadow ray (begin_shade_lit), so a frame takes about D + 2
+// big rounds (+1 per extra light a stale-specular scan needs); the other kernels / literal mode take one ray per
+// round. The arithmetic
 // is the same set of device functions as the monolithic kernel (rt_device.h), only the control flow is cut
 // at the traversal calls; tests require both paths to agree bit for bit.
 #include "rt_kernels.h"
 #include "rt_grid.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace rt {
 
 // ---- per-pixel state, struct-of-arrays: field f of pixel i at st[f * n + i] ------------------------------------
 enum : uint32_t {
-    F_SX, F_SY, F_SZ, F_SW, F_DX, F_DY, F_DZ, F_DW,          // the ray in flight: ONE 32-byte record per pixel (store_ray)
-    F_RES_T, F_RES_I,                                          // trace result: t / index, or occluded flag
+    F_SX, F_SY, F_SZ, F_SW, F_DX, F_DY, F_DZ, F_DW,          // closest-hit ray in flight (primary / reflection): ONE 32-byte record per pixel
+    F_A0, F_A1, F_A2, F_A3, F_A4, F_A5, F_A6, F_A7,          // shadow ray in flight: a second 32-byte record (store_ray, slot 1)
+    F_RES_T, F_RES_I,                                          // closest-hit result: t / index
+    F_RES_ANY,                                                 // shadow-ray result: 1 lit, 0 occluded
     F_PX, F_PY, F_PZ, F_PW, F_NX, F_NY, F_NZ, F_RX, F_RY, F_RZ, F_HIDX,  // hit being shaded
     F_LI,                                                      // light index of the shadow ray in flight
     F_AR, F_AG, F_AB, F_DR, F_DG, F_DB, F_SR, F_SG, F_SB,      // light-loop terms carried between rounds
@@ -34,6 +39,9 @@ enum : uint32_t {
     F_COUNT
 };
 enum : uint32_t { PH_DONE = 0, PH_PRIMARY = 1, PH_SHADOW_PRIMARY = 2, PH_SHADOW_REFLECT = 3, PH_REFLECT = 4 };
+// flag on the phase word: the reflection ray that leaves the hit being shaded is already in flight / traced (its ray
+// in slot 0, its result in F_RES_T / F_RES_I) - see begin_shade
+constexpr uint32_t PH_FLAG_REFLECTION_SENT = 0x100u;
 
 struct WfParams {
     RenderParams rp;
@@ -68,17 +76,19 @@ __device__ __forceinline__ uint32_t& U(const WfParams& w, uint32_t f, uint64_t i
     return reinterpret_cast<uint32_t*>(w.st)[(uint64_t)f * w.rp.n_local + i];
 }
 
-// The ray in flight is the one record the trace kernels read per lane at scattered pixel ids (a lane takes a new
-// ray whenever its old one ends), so it is kept as one 32-byte record per pixel in the space of the first eight
-// fields: two 16-byte loads from one cache line instead of eight 4-byte loads from eight lines.
-__device__ __forceinline__ void store_ray(const WfParams& w, uint64_t i, const Ray& r) {
-    float4* slot = reinterpret_cast<float4*>(w.st) + 2 * i;
-    slot[0] = make_float4(r.sx, r.sy, r.sz, r.sw);
-    slot[1] = make_float4(r.dx, r.dy, r.dz, r.dw);
+// A ray in flight is the one record the trace kernels read per lane at scattered pixel ids (a lane takes a new
+// ray whenever its old one ends), so it is kept as one 32-byte record per pixel: two 16-byte loads from one cache
+// line instead of eight 4-byte loads from eight lines. Two slots, in the space of the first sixteen fields: 0 for
+// the closest-hit ray (primary / reflection), 1 for the shadow ray - a pixel can have one of each in flight.
+constexpr uint32_t kSlotClosest = 0, kSlotShadow = 1;
+__device__ __forceinline__ void store_ray(const WfParams& w, uint64_t i, const Ray& r, uint32_t slot) {
+    float4* rec = reinterpret_cast<float4*>(w.st) + 2 * ((uint64_t)slot * w.rp.n_local + i);
+    rec[0] = make_float4(r.sx, r.sy, r.sz, r.sw);
+    rec[1] = make_float4(r.dx, r.dy, r.dz, r.dw);
 }
-__device__ __forceinline__ Ray load_ray(const WfParams& w, uint64_t i) {
-    const float4* slot = reinterpret_cast<const float4*>(w.st) + 2 * i;
-    const float4 s = slot[0], d = slot[1];
+__device__ __forceinline__ Ray load_ray(const WfParams& w, uint64_t i, uint32_t slot) {
+    const float4* rec = reinterpret_cast<const float4*>(w.st) + 2 * ((uint64_t)slot * w.rp.n_local + i);
+    const float4 s = rec[0], d = rec[1];
     Ray r;
     r.sx = s.x; r.sy = s.y; r.sz = s.z; r.sw = s.w;
     r.dx = d.x; r.dy = d.y; r.dz = d.z; r.dw = d.w;
@@ -179,7 +189,7 @@ __device__ __forceinline__ bool begin_pixel(const WfParams& w, uint64_t i) {
         ray.sx = s.x; ray.sy = s.y; ray.sz = s.z; ray.sw = s.w;
         ray.dx = d.x; ray.dy = d.y; ray.dz = d.z; ray.dw = d.w;
     }
-    store_ray(w, i, ray);
+    store_ray(w, i, ray, kSlotClosest);
     U(w, F_PHASE, i) = PH_PRIMARY;
     return true;
 }
@@ -190,7 +200,7 @@ __global__ __launch_bounds__(256) void wf_trace_closest(const WfParams w, uint32
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_queue) return;
     const uint64_t i = w.q_prev_closest[t];
-    const Ray ray = load_ray(w, i);
+    const Ray ray = load_ray(w, i, kSlotClosest);
     float T = kMaxFloat;
     int idx = -1;
     closest_hit<FUSED, DW0>(w.rp.scene.pairs, w.rp.scene.n_pairs, ray, T, idx);
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(256) void wf_trace_closest_grid(const WfParams w, u
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_queue) return;
     const uint64_t i = w.q_prev_closest[t];
-    const Ray ray = load_ray(w, i);
+    const Ray ray = load_ray(w, i, kSlotClosest);
     float T = kMaxFloat;
     int idx = -1;
     uint32_t tested = 0;
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams w, 
     if (t >= n_queue) return;
     const RenderParams& p = w.rp;
     const uint64_t i = w.q_prev_closest[t];
-    const Ray ray = load_ray(w, i);
+    const Ray ray = load_ray(w, i, kSlotClosest);
     const uint64_t px = pixel_of(p, i);
     uint64_t g = px;
     if (p.world > 1u) {
@@ -352,7 +362,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             if (st == 0 && mine < seg_end) {
                 if (STATS) ++s_rays;
                 pix = queue[mine];
-                ray = load_ray(w, pix);
+                ray = load_ray(w, pix, ANY ? kSlotShadow : kSlotClosest);
                 ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
                 T = kMaxFloat; idx = -1; cur_sphere = false; pend = false;
                 bool done = false;
@@ -371,7 +381,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 if (!done) w0 = walk_begin(g, ray, ANY ? 1.0f + slack : 3.0e38f);
                 wk = lean_walk(g, w0);
                 if (done || !w0.alive) {  // occluded by an always-object, or the ray misses the grid box
-                    if (ANY) U(w, F_RES_I, pix) = done ? 0u : 1u;
+                    if (ANY) U(w, F_RES_ANY, pix) = done ? 0u : 1u;
                     else { F(w, F_RES_T, pix) = T; U(w, F_RES_I, pix) = (uint32_t)idx; }
                 } else {
                     st = 1;
@@ -429,7 +439,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                     if (STATS) ++tested;
                     pend = false;
                     if (ANY) {
-                        if (occludes<FUSED>(type, sx, sy, sz, dx, dy, dz)) { U(w, F_RES_I, pix) = 0u; st = 0; }
+                        if (occludes<FUSED>(type, sx, sy, sz, dx, dy, dz)) { U(w, F_RES_ANY, pix) = 0u; st = 0; }
                     } else {
                         closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, pend_k, T, idx, cur_sphere);
                     }
@@ -438,7 +448,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         }
         // ---- a finished walk with nothing parked: the ray is done ----
         if (st == 3 && !pend) {
-            if (ANY) U(w, F_RES_I, pix) = 1u;  // nothing in the way
+            if (ANY) U(w, F_RES_ANY, pix) = 1u;  // nothing in the way
             else { F(w, F_RES_T, pix) = T; U(w, F_RES_I, pix) = (uint32_t)idx; }
             st = 0;
         }
@@ -471,11 +481,11 @@ __global__ __launch_bounds__(256) void wf_trace_any_literal(const WfParams w, ui
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_queue) return;
     const uint64_t i = w.q_prev_any[t];
-    const Ray ray = load_ray(w, i);
+    const Ray ray = load_ray(w, i, kSlotShadow);
     float T = kMaxFloat;
     int idx = -1;
     closest_hit<FUSED, true>(w.rp.scene.pairs, w.rp.scene.n_pairs, ray, T, idx);
-    U(w, F_RES_I, i) = (T >= 1.f || T < 0) ? 1u : 0u;
+    U(w, F_RES_ANY, i) = (T >= 1.f || T < 0) ? 1u : 0u;
     const unsigned long long lanes = (unsigned long long)__popcll(__ballot(true));
     if (w.count_rays && (threadIdx.x & 63u) == 0u)
         atomicAdd(&w.rp.counters->tests, 2ull * w.rp.scene.n_pairs * lanes);
@@ -494,7 +504,7 @@ __global__ __launch_bounds__(256) void wf_trace_any_slice(const WfParams w, cons
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_queue) return;
     const uint32_t i = q_in[t];
-    const Ray ray = load_ray(w, i);
+    const Ray ray = load_ray(w, i, kSlotShadow);
     uint32_t visited = 0;
     const bool occluded = any_hit_before_one<FUSED>(w.shadow_pairs + pair_lo, pair_hi - pair_lo, ray, &visited);
     if (w.count_rays) {  // `visited` is wave-uniform: every lane rides along until the wave leaves
@@ -503,9 +513,9 @@ __global__ __launch_bounds__(256) void wf_trace_any_slice(const WfParams w, cons
             atomicAdd(&w.rp.counters->tests, 2ull * visited * lanes);
     }
     if (occluded) {
-        U(w, F_RES_I, i) = 0u;
+        U(w, F_RES_ANY, i) = 0u;
     } else {
-        if (first_slice) U(w, F_RES_I, i) = 1u;  // lit unless a later slice says otherwise
+        if (first_slice) U(w, F_RES_ANY, i) = 1u;  // lit unless a later slice says otherwise
         if (q_out) push(q_out, out_count, i);
     }
 }
@@ -516,6 +526,7 @@ struct Ctx {
     uint64_t i;
     unsigned long long traced, reference, hits;
     bool want_closest, want_any;  // the pixel queued a ray for the next round (appended by block_push at the end)
+    uint32_t flags;               // PH_FLAG_* bits of the pixel's phase word
 };
 
 template <int KERNEL>
@@ -534,7 +545,7 @@ __device__ __forceinline__ void emit_shadow(Ctx& c, const HitRec& h, uint32_t li
     normalize3(vvx, vvy, vvz);
     LightGeom g;
     light_geometry<FUSED>(S.lights[li], h, nvx, nvy, nvz, vvx, vvy, vvz, g);
-    store_ray(c.w, c.i, g.shadow);
+    store_ray(c.w, c.i, g.shadow, kSlotShadow);
     U(c.w, F_LI, c.i) = li;
     U(c.w, F_PHASE, c.i) = phase;
     c.want_any = true;
@@ -543,17 +554,38 @@ __device__ __forceinline__ void emit_shadow(Ctx& c, const HitRec& h, uint32_t li
 
 template <int KERNEL, bool FUSED> __device__ void shade_done(Ctx& c, const HitRec& h, bool primary, float cr, float cg, float cb);
 
-// start shading hit `h` (light loop of shade(), shade_and_reflect_kernel.cl:193): first shadow ray, or done if L == 0
+// Start shading hit `h` when there is at least one light (light loop of shade(), shade_and_reflect_kernel.cl:193):
+// queue the first shadow ray. In shade_and_reflect the reflection ray that leaves this hit depends on the hit and
+// on the loop state (bounces left, absorption so far), not on the colour the light loop is about to produce - so
+// it is queued NOW, next to the shadow ray, with exactly the condition loop_step() will evaluate after the
+// shading (`bounces > 0 && absorptionPercent <= 0.999`, the latter already including this hit). A frame then needs
+// D + 2 big rounds instead of 2D + 2, every round traces shadow and reflection rays side by side, and wf_resume
+// touches the pixel state half as often. `spec_bounces` / `spec_ap`: the loop state as it will be after this hit.
 template <int KERNEL, bool FUSED>
-__device__ __forceinline__ void begin_shade(Ctx& c, const HitRec& h, bool primary) {
+__device__ __forceinline__ void begin_shade_lit(Ctx& c, const HitRec& h, bool primary, uint32_t spec_bounces, float spec_ap) {
     const Scene& S = c.w.rp.scene;
     store_hit(c.w, c.i, h);
     c.reference += S.n_lights;
-    if (S.n_lights == 0) { shade_done<KERNEL, FUSED>(c, h, primary, 0.f, 0.f, 0.f); return; }
+    uint32_t flag = 0u;
+    if (KERNEL == 2 && !S.literal && spec_bounces > 0u && spec_ap <= 0.999f) {
+        Ray ray;
+        reflection_ray<FUSED>(h, ray);
+        store_ray(c.w, c.i, ray, kSlotClosest);
+        c.want_closest = true;
+        c.traced += 1;
+        flag = PH_FLAG_REFLECTION_SENT;
+    }
     const bool forward = (KERNEL == 1) || S.literal;
     // the carried light-loop terms start at zero: resume_shadow() knows the first light of a scan and does not
     // read them, so nothing is written here
-    emit_shadow<FUSED>(c, h, forward ? 0u : S.n_lights - 1u, primary ? PH_SHADOW_PRIMARY : PH_SHADOW_REFLECT);
+    emit_shadow<FUSED>(c, h, forward ? 0u : S.n_lights - 1u, (primary ? PH_SHADOW_PRIMARY : PH_SHADOW_REFLECT) | flag);
+}
+
+// ... or, without lights, go straight on (shade() returns black)
+template <int KERNEL, bool FUSED>
+__device__ __forceinline__ void begin_shade(Ctx& c, const HitRec& h, bool primary, uint32_t spec_bounces, float spec_ap) {
+    if (c.w.rp.scene.n_lights == 0) { store_hit(c.w, c.i, h); shade_done<KERNEL, FUSED>(c, h, primary, 0.f, 0.f, 0.f); return; }
+    begin_shade_lit<KERNEL, FUSED>(c, h, primary, spec_bounces, spec_ap);
 }
 
 // one light-loop iteration, resumed with the visibility of light `li`; mirrors shade_forward /
@@ -564,7 +596,7 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
     const uint64_t i = c.i;
     const HitRec h = load_hit(c.w, i);
     const uint32_t li = U(c.w, F_LI, i);
-    const bool lit = U(c.w, F_RES_I, i) != 0u;
+    const bool lit = U(c.w, F_RES_ANY, i) != 0u;
     const ColdObject* co = S.cold + h.index;
     const float4 amb = co->amb_absorb, dif = co->dif_shine, spec = co->spec_type;
     float nvx = h.nx, nvy = h.ny, nvz = h.nz;
@@ -574,7 +606,7 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
     const LightRec L = S.lights[li];
     LightGeom g;
     light_geometry<FUSED>(L, h, nvx, nvy, nvz, vvx, vvy, vvz, g);
-    const uint32_t phase = primary ? PH_SHADOW_PRIMARY : PH_SHADOW_REFLECT;
+    const uint32_t phase = (primary ? PH_SHADOW_PRIMARY : PH_SHADOW_REFLECT) | c.flags;
     const bool forward = (KERNEL == 1) || S.literal;
     const bool first_of_scan = forward ? (li == 0u) : (li == S.n_lights - 1u);  // carried terms are still all zero
     float sr = 0.f, sg = 0.f, sb = 0.f;
@@ -648,6 +680,16 @@ __device__ __forceinline__ void finish_reflect(Ctx& c, bool fused, float abr, fl
     write_pixel<2>(c, abr, abg, abb);
 }
 
+// the state a pixel carries across a reflection trace
+__device__ __forceinline__ void store_loop_state(Ctx& c, float abr, float abg, float abb, float rr, float rg, float rb, float ap,
+                                                 uint32_t bounces) {
+    const uint64_t i = c.i;
+    F(c.w, F_ABR, i) = abr; F(c.w, F_ABG, i) = abg; F(c.w, F_ABB, i) = abb;
+    F(c.w, F_RR, i) = rr; F(c.w, F_RG, i) = rg; F(c.w, F_RB, i) = rb;
+    F(c.w, F_AP, i) = ap;
+    U(c.w, F_BOUNCES, i) = bounces;
+}
+
 // top of one iteration of `while (bounces-- > 0 && raycast(...) && absorptionPercent <= 0.999f)` (:268)
 template <bool FUSED>
 __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr, float abg, float abb, float rr, float rg,
@@ -659,15 +701,26 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
     c.reference += 1;
     const bool absorbing = (ap <= 0.999f);
     if (!absorbing && !S.literal) { finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces); return; }
+    if (c.flags & PH_FLAG_REFLECTION_SENT) {
+        // the ray left together with this hit's first shadow ray (begin_shade_lit) and has been traced: carry on
+        // with its result, as the PH_REFLECT branch of wf_resume does one round later in the other modes
+        const uint64_t i = c.i;
+        const float T = F(c.w, F_RES_T, i);
+        if (T == kMaxFloat) { finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces); return; }
+        const int idx = (int)U(c.w, F_RES_I, i);
+        const Ray ray = load_ray(c.w, i, kSlotClosest);
+        HitRec rh;
+        materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
+        store_loop_state(c, abr, abg, abb, rr, rg, rb, ap, bounces);
+        const float ra = (1.f - ap) * S.cold[rh.index].amb_absorb.w;  // shade_done's update, ahead of time
+        begin_shade_lit<2, FUSED>(c, rh, false, bounces, ap + ra);
+        return;
+    }
     Ray ray;
     reflection_ray<FUSED>(from, ray);
-    store_ray(c.w, c.i, ray);
-    const uint64_t i = c.i;
-    F(c.w, F_ABR, i) = abr; F(c.w, F_ABG, i) = abg; F(c.w, F_ABB, i) = abb;
-    F(c.w, F_RR, i) = rr; F(c.w, F_RG, i) = rg; F(c.w, F_RB, i) = rb;
-    F(c.w, F_AP, i) = ap;
-    U(c.w, F_BOUNCES, i) = bounces;
-    U(c.w, F_PHASE, i) = PH_REFLECT;
+    store_ray(c.w, c.i, ray, kSlotClosest);
+    store_loop_state(c, abr, abg, abb, rr, rg, rb, ap, bounces);
+    U(c.w, F_PHASE, c.i) = PH_REFLECT;
     c.want_closest = true;
     c.traced += 1;
 }
@@ -695,13 +748,18 @@ template <int KERNEL, bool FUSED>
 __global__ __launch_bounds__(kResumeThreads) void wf_resume(const WfParams w) {
     const uint32_t t = blockIdx.x * kResumeThreads + threadIdx.x;
     const uint32_t total = w.n_prev_closest + w.n_prev_any;
-    Ctx c{w, 0, 0ull, 0ull, 0ull, false, false};
+    Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u};
     if (t < total) {
         const uint64_t i = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
         c.i = i;
         const Scene& S = w.rp.scene;
-        const uint32_t phase = U(w, F_PHASE, i);
-        if (phase == PH_PRIMARY) {
+        const uint32_t word = U(w, F_PHASE, i);
+        const uint32_t phase = word & 0xffu;
+        c.flags = word & ~0xffu;
+        // a pixel with a shadow AND a reflection ray in flight sits in both queues: it is resumed from its shadow entry
+        const bool duplicate = (t < w.n_prev_closest) && (phase == PH_SHADOW_PRIMARY || phase == PH_SHADOW_REFLECT);
+        if (duplicate) {
+        } else if (phase == PH_PRIMARY) {
             const float T = F(w, F_RES_T, i);
             const int idx = (int)U(w, F_RES_I, i);
             const bool hit = (KERNEL == 2) ? !(T == kMaxFloat) : (T < kMaxFloat);
@@ -714,10 +772,10 @@ __global__ __launch_bounds__(kResumeThreads) void wf_resume(const WfParams w) {
             } else if (!hit) {
                 write_pixel<KERNEL>(c, 0.f, 0.f, 0.f);
             } else {
-                const Ray ray = load_ray(w, i);
+                const Ray ray = load_ray(w, i, kSlotClosest);
                 HitRec h;
                 materialise<FUSED>(S.hot, S.cold, idx, T, ray, h);
-                begin_shade<KERNEL, FUSED>(c, h, true);
+                begin_shade<KERNEL, FUSED>(c, h, true, w.rp.max_bounces, S.cold[h.index].amb_absorb.w);
             }
         } else if (phase == PH_SHADOW_PRIMARY) {
             resume_shadow<KERNEL, FUSED>(c, true);
@@ -733,10 +791,10 @@ __global__ __launch_bounds__(kResumeThreads) void wf_resume(const WfParams w) {
             if (T == kMaxFloat || !(ap <= 0.999f)) {  // raycast() false, or the absorption test of the loop condition
                 finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces);
             } else {
-                const Ray ray = load_ray(w, i);
+                const Ray ray = load_ray(w, i, kSlotClosest);
                 HitRec rh;
                 materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
-                begin_shade<KERNEL, FUSED>(c, rh, false);
+                begin_shade<KERNEL, FUSED>(c, rh, false, bounces, ap + (1.f - ap) * S.cold[rh.index].amb_absorb.w);
             }
         }
     }
@@ -801,6 +859,21 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
         w.n_prev_any = na;
         const bool use_grid = w.grid.enabled && !w.rp.scene.literal;
         if (use_grid && (e = hipMemsetAsync(buf.counts + 4, 0, 2 * sizeof(uint32_t), stream)) != hipSuccess) return e;
+        // The two launches of a round are independent (different rays, different result words): through the grid they
+        // run side by side on two streams, so that each fills the other's tail and a small light-scan queue hides
+        // behind a big reflection queue.
+        static const bool one_stream = std::getenv("RT_WF_ONE_STREAM") != nullptr;  // measurement knob
+        const bool side_by_side = use_grid && nc && na && buf.side_stream && !one_stream;
+        hipStream_t any_stream = stream;
+        if (side_by_side) {
+            any_stream = buf.side_stream;
+            if ((e = hipEventRecord(buf.ev_fork, stream)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(any_stream, buf.ev_fork, 0)) != hipSuccess) return e;
+            if (w.count_rays) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, true, true>), persistent_grid(na), dim3(256), 0, any_stream, w, (const uint32_t*)w.q_prev_any, na, buf.counts + 5);
+            else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, true, false>), persistent_grid(na), dim3(256), 0, any_stream, w, (const uint32_t*)w.q_prev_any, na, buf.counts + 5);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if ((e = hipEventRecord(buf.ev_join, any_stream)) != hipSuccess) return e;
+        }
         if (nc) {
             if (use_grid && first && w.tiles.enabled && w.rp.pinhole) {
                 hipLaunchKernelGGL((wf_trace_primary_tiles<FUSED>), grid_for(nc), dim3(256), 0, stream, w, nc);
@@ -814,7 +887,9 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
             }
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
-        if (na) {
+        if (side_by_side) {
+            if ((e = hipStreamWaitEvent(stream, buf.ev_join, 0)) != hipSuccess) return e;
+        } else if (na) {
             if (w.rp.scene.literal) {
                 hipLaunchKernelGGL((wf_trace_any_literal<FUSED>), grid_for(na), dim3(256), 0, stream, w, na);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
