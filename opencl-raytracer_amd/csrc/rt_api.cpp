@@ -661,13 +661,29 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
             if (!(rg[i] >= 0) || !std::isfinite(rg[i])) continue;
             int x0, x1, y0, y1, z0, z1;
             range(i, 0, x0, x1); range(i, 1, y0, y1); range(i, 2, z0, z1);
-            for (int z = z0; z <= z1; ++z)
-                for (int y = y0; y <= y1; ++y)
+            // of the cells its box touches, only those the registration SPHERE reaches (distance from the centre to
+            // the cell's box <= radius, cell walls taken from the kernels' float origin / edge, radius already
+            // holding 0.01 cell of slack): a quarter fewer entries for spheres that are small against a cell
+            const double cc[3] = {sph[i].x, sph[i].y, sph[i].z};
+            const double r2 = rg[i] * rg[i];
+            auto gap2 = [&](int a, int k) {  // squared distance from the centre to slab k of axis a
+                const double w0 = (double)lof[a] + (double)cellf * k, w1 = w0 + (double)cellf;
+                const double d = cc[a] < w0 ? w0 - cc[a] : (cc[a] > w1 ? cc[a] - w1 : 0.0);
+                return d * d;
+            };
+            for (int z = z0; z <= z1; ++z) {
+                const double dz2 = gap2(2, z);
+                for (int y = y0; y <= y1; ++y) {
+                    const double dyz2 = dz2 + gap2(1, y);
+                    if (dyz2 > r2) continue;
                     for (int x = x0; x <= x1; ++x) {
+                        if (dyz2 + gap2(0, x) > r2) continue;
                         const size_t cidx = ((size_t)z * dim[1] + y) * dim[0] + x;
                         if (pass == 0) start[cidx + 1] += 1;
                         else entries[fill[cidx]++] = i;
                     }
+                }
+            }
         }
         if (pass == 0) {
             for (size_t k = 0; k < n_cells; ++k) start[k + 1] += start[k];
