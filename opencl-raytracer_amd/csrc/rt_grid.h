@@ -33,6 +33,16 @@
 
 namespace rt {
 
+// How far past the current best hit (closest) or past t = 1 (shadow) a walk continues, in cell edges. An object
+// whose computed t is <= the current best has the point start + t dir inside its registration sphere (the sphere
+// holds the surface plus the fp32 error of t, which is ~1e-6 of the distances involved), i.e. it is registered in
+// the cell that contains that point - a cell the walk enters at a parameter <= t. The slack only has to cover the
+// walk's own rounding; half a cell is 3-4 orders of magnitude more than that.
+#ifndef RT_WALK_SLACK
+#define RT_WALK_SLACK 0.5f
+#endif
+constexpr float kWalkSlackCells = RT_WALK_SLACK;
+
 struct GridDesc {
     float lox, loy, loz;        // grid origin (view space)
     float inv_cell;             // 1 / cell edge
@@ -252,7 +262,7 @@ __device__ __forceinline__ void closest_hit_grid(const GridDesc& g, const HotObj
     // two more cells after the best hit's cell (the candidate's own t is exact; the slack covers objects that
     // start in the next cells but whose computed t the reference may place marginally earlier)
     const float len = __builtin_sqrtf(ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz);
-    const float slack = len > 0.f ? 2.0f * g.cell / len : 3.0e38f;
+    const float slack = len > 0.f ? kWalkSlackCells * g.cell / len : 3.0e38f;
     for (;;) {
         const uint32_t c = ((uint32_t)w.iz * (uint32_t)g.ny + (uint32_t)w.iy) * (uint32_t)g.nx + (uint32_t)w.ix;
         const uint2 range = g.cell_range[c];

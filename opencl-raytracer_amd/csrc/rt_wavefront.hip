@@ -376,7 +376,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                     else closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, k, T, idx, cur_sphere);
                 }
                 dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
-                slack = dd > 0.f ? 2.0f * g.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
+                slack = dd > 0.f ? kWalkSlackCells * g.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
                 Walk w0 = {};
                 if (!done) w0 = walk_begin(g, ray, ANY ? 1.0f + slack : 3.0e38f);
                 wk = lean_walk(g, w0);
