@@ -74,6 +74,7 @@ struct rt_context {
     uint32_t* d_tile_entries = nullptr;
     rt::ScreenTiles tiles = {};
     bool tiles_dirty = true;
+    bool has_triangles = false;             // type-2 records (extension): only the grid path knows them
     bool affine_w = true;                   // every mv / mvInverse has bottom row (0,0,0,1) exactly
     bool primary_w_one = true;              // every uploaded primary ray has start.w == 1
     double origin_lo[3] = {0, 0, 0}, origin_hi[3] = {0, 0, 0};  // box of the primary ray origins
@@ -146,6 +147,17 @@ void repack_objects(const rt_object_data* objs, uint32_t n, std::vector<rt::HotP
         h.row2 = make_float4(m[2], m[6], m[10], m[14]);
         h.type = o.type;
         h.pad[0] = h.pad[1] = h.pad[2] = 0;
+        if (o.type == 2u) {
+            // triangle (extension): mv columns 0..2 = vertices, mvInverse column 0 = guard
+            // sphere; the edges are single fp32 subtractions, exactly what the CPU statement computes per ray
+            const float* v = o.mv;
+            const volatile float e1x = v[4] - v[0], e1y = v[5] - v[1], e1z = v[6] - v[2];
+            const volatile float e2x = v[8] - v[0], e2y = v[9] - v[1], e2z = v[10] - v[2];
+            h.row0 = make_float4(v[0], v[1], v[2], m[0]);
+            h.row1 = make_float4(e1x, e1y, e1z, m[1]);
+            h.row2 = make_float4(e2x, e2y, e2z, m[2]);
+            std::memcpy(&h.pad[0], &m[3], 4);
+        }
         rt::ColdObject& c = cold[i];
         std::memcpy(c.mv, o.mv, sizeof(c.mv));
         c.inv_row3 = make_float4(m[3], m[7], m[11], m[15]);
@@ -173,7 +185,13 @@ struct Bound { double x, y, z, r, kappa2; };
 Bound object_bound(const rt_object_data& o) {
     const double inf = std::numeric_limits<double>::infinity();
 #define make_float4(X, Y, Z, R) Bound{(double)(X), (double)(Y), (double)(Z), (double)(R), 1.0}
-    if (o.type > 1u) return make_float4(0.f, 0.f, 0.f, -inf);
+    if (o.type == 2u) {  // triangle: the record's guard sphere bounds every hit (the test itself demands it)
+        const float* gs = o.mvInverse;
+        if (!std::isfinite(gs[0] + gs[1] + gs[2]) || !(gs[3] >= 0.f)) return make_float4(0.f, 0.f, 0.f, -inf);  // never passes its guard
+        if (!std::isfinite(gs[3])) return make_float4(0.f, 0.f, 0.f, inf);
+        return make_float4(gs[0], gs[1], gs[2], gs[3]);
+    }
+    if (o.type > 2u) return make_float4(0.f, 0.f, 0.f, -inf);
     const float* m = o.mvInverse;
     double A[3][3] = {{m[0], m[4], m[8]}, {m[1], m[5], m[9]}, {m[2], m[6], m[10]}};
     const double b[3] = {m[12], m[13], m[14]};
@@ -338,6 +356,7 @@ constexpr uint32_t kWavefrontMinObjects = 512;      // brute-force wavefront
 constexpr uint32_t kWavefrontGridMinObjects = 96;   // wavefront when the conservative grid is available
 
 bool use_wavefront(const rt_context* c) {
+    if (c->has_triangles) return true;
     if (c->flags & RT_FLAG_WAVEFRONT) return true;
     if (c->flags & RT_FLAG_MONOLITHIC) return false;
     if (c->n_objs >= kWavefrontMinObjects) return true;
@@ -584,6 +603,27 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     double cell = std::cbrt(std::max(ext[0], 1e-6) * std::max(ext[1], 1e-6) * std::max(ext[2], 1e-6) / (cells_per_object * n));
     cell = std::max(cell, std::max(ext[0], std::max(ext[1], ext[2])) / 256.0);
     if (!(cell > 0) || !std::isfinite(cell)) return RT_OK;
+    // Objects that crowd on surfaces (tessellated meshes) leave most of such a grid empty and pile up in the rest:
+    // refine while an occupied cell holds more than four object centres on average (random clouds: ~1.3, no change)
+    {
+        const double max_ext = std::max(ext[0], std::max(ext[1], ext[2]));
+        std::vector<uint64_t> keys;
+        for (int attempt = 0; attempt < 8 && max_ext / (cell * 0.7) < 280.0; ++attempt) {
+            keys.clear();
+            keys.reserve(n);
+            for (uint32_t i = 0; i < n; ++i) {
+                if (!std::isfinite(sph[i].r)) continue;
+                const uint64_t kx = (uint64_t)std::max(0.0, std::floor((sph[i].x - lo[0]) / cell));
+                const uint64_t ky = (uint64_t)std::max(0.0, std::floor((sph[i].y - lo[1]) / cell));
+                const uint64_t kz = (uint64_t)std::max(0.0, std::floor((sph[i].z - lo[2]) / cell));
+                keys.push_back((kz << 42) | (ky << 21) | kx);
+            }
+            std::sort(keys.begin(), keys.end());
+            const size_t distinct = (size_t)(std::unique(keys.begin(), keys.end()) - keys.begin());
+            if (distinct == 0 || (double)keys.size() / (double)distinct <= 4.0) break;
+            cell *= 0.7;
+        }
+    }
     // Radii (rt_grid.h derives the bound): with u = 2^-24, a ray that starts `dist` from the centre c of an object
     // with bounding radius R and condition number kappa can only be accepted by the reference's fp32 test if its
     // line passes c within
@@ -835,8 +875,11 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
     RT_TRY(hipMalloc((void**)&c->d_lights, sizeof(rt::LightRec) * (size_t)(n_lights + 1)));
     if (n_lights) RT_TRY(hipMemcpy(c->d_lights, lights, sizeof(rt::LightRec) * n_lights, hipMemcpyHostToDevice));
 
+    for (uint32_t i = 0; i < n_objs; ++i)
+        if (static_cast<const rt_object_data*>(objs)[i].type == 2u) { c->has_triangles = true; break; }
     for (uint32_t i = 0; i < n_objs && c->affine_w; ++i) {
         const rt_object_data& o = static_cast<const rt_object_data*>(objs)[i];
+        if (o.type == 2u) continue;  // vertices, not matrices
         c->affine_w = o.mv[3] == 0.f && o.mv[7] == 0.f && o.mv[11] == 0.f && o.mv[15] == 1.f && o.mvInverse[3] == 0.f &&
                       o.mvInverse[7] == 0.f && o.mvInverse[11] == 0.f && o.mvInverse[15] == 1.f;
     }
@@ -866,9 +909,15 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         }
     }
 #undef RT_TRY
-    if (n_objs >= kWavefrontGridMinObjects || (flags & RT_FLAG_WAVEFRONT)) {
+    if (n_objs >= kWavefrontGridMinObjects || (flags & RT_FLAG_WAVEFRONT) || c->has_triangles) {
         rc = build_grid(c, static_cast<const rt_object_data*>(objs), n_objs);
         if (rc != RT_OK) return bail(rc);
+    }
+    if (c->has_triangles && (!c->grid.enabled || (flags & (RT_FLAG_LITERAL | RT_FLAG_MONOLITHIC | RT_FLAG_NO_GRID)))) {
+        fail(c, RT_ERR_INVALID_ARGUMENT,
+             "triangle records (type 2, an extension of the reference's two primitives) are traced by the grid path only: "
+             "it needs affine instances, ray w = 1, and none of RT_FLAG_LITERAL / RT_FLAG_MONOLITHIC / RT_FLAG_NO_GRID");
+        return bail(RT_ERR_INVALID_ARGUMENT);
     }
     *out_ctx = c;
     return RT_OK;

@@ -34,8 +34,10 @@ struct HotObject {   // 64 B, 64-B aligned: one s_load_dwordx16 per object per w
     float4 row0;     // mvInverse row 0: (m[0], m[4], m[8],  m[12])
     float4 row1;     // mvInverse row 1: (m[1], m[5], m[9],  m[13])
     float4 row2;     // mvInverse row 2: (m[2], m[6], m[10], m[14])
-    uint32_t type;   // 0 sphere, 1 box, anything else: never hit (the reference's switch has no default)
+    uint32_t type;   // 0 sphere, 1 box, 2 triangle (extension), anything else: never hit (the reference's switch has no default)
     uint32_t pad[3];
+    // type 2 (triangle, extension - DESIGN.md section 11): row0 = (v0, cx), row1 = (v1 - v0, cy), row2 = (v2 - v0, cz),
+    // pad[0] = bits of R; (c, R) is the record's guard sphere
 };
 struct ColdObject {  // 128 B
     float mv[16];        // column-major, as uploaded
@@ -186,6 +188,38 @@ __device__ __forceinline__ bool box_line_misses(float sx, float sy, float sz, fl
     const float B = sx * dx + sy * dy + sz * dz;
     const float disc = B * B - A * (ss - 1.0f);
     return ss < 1.0e5f && disc < 0.0f;
+}
+
+// EXTENSION, no reference semantics (spec: DESIGN.md section 11; CPU statement: oracle/rt_oracle.c triangle_hit):
+// triangle with vertices in view space. fp32, no contraction in either flavour, sums left to right, IEEE division.
+// A ray is only tested if its line passes the record's guard sphere, which makes every accepted hit local.
+__device__ __forceinline__ bool triangle_candidate(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x,
+                                                   float e2y, float e2z, float cx, float cy, float cz, float R, const Ray& ray,
+                                                   float& t) {
+    const float ocx = cx - ray.sx, ocy = cy - ray.sy, ocz = cz - ray.sz;
+    const float oo = ocx * ocx + ocy * ocy + ocz * ocz;
+    const float od = ocx * ray.dx + ocy * ray.dy + ocz * ray.dz;
+    const float dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
+    const float disc = od * od - dd * (oo - R * R);
+    if (disc < 0) return false;
+    const float px = ray.dy * e2z - ray.dz * e2y;
+    const float py = ray.dz * e2x - ray.dx * e2z;
+    const float pz = ray.dx * e2y - ray.dy * e2x;
+    const float det = e1x * px + e1y * py + e1z * pz;
+    if (!(det != 0)) return false;
+    const float inv = 1.0f / det;
+    const float tx = ray.sx - v0x, ty = ray.sy - v0y, tz = ray.sz - v0z;
+    const float u = (tx * px + ty * py + tz * pz) * inv;
+    if (!(u >= 0 && u <= 1)) return false;
+    const float qx = ty * e1z - tz * e1y;
+    const float qy = tz * e1x - tx * e1z;
+    const float qz = tx * e1y - ty * e1x;
+    const float v = (ray.dx * qx + ray.dy * qy + ray.dz * qz) * inv;
+    if (!(v >= 0 && u + v <= 1)) return false;
+    const float tt = (e2x * qx + e2y * qy + e2z * qz) * inv;
+    if (!(tt >= 0)) return false;
+    t = tt;
+    return true;
 }
 
 // unit box [-0.5,0.5]^3 (shade_and_reflect_kernel.cl:123-144)
@@ -470,6 +504,24 @@ __device__ __forceinline__ void materialise(const HotObject* __restrict__ hot, c
                                             int index, float t, const Ray& ray, HitRec& h) {
     const HotObject* o = hot + index;
     const ColdObject* c = cold + index;
+    if (o->type == 2u) {  // triangle (extension): view-space point on the ray, normal = normalize(e1 x e2)
+        const float4 e1 = o->row1, e2 = o->row2;
+        h.px = fma_<FUSED>(t, ray.dx, ray.sx);
+        h.py = fma_<FUSED>(t, ray.dy, ray.sy);
+        h.pz = fma_<FUSED>(t, ray.dz, ray.sz);
+        h.pw = fma_<FUSED>(t, ray.dw, ray.sw);
+        float nx = e1.y * e2.z - e1.z * e2.y;
+        float ny = e1.z * e2.x - e1.x * e2.z;
+        float nz = e1.x * e2.y - e1.y * e2.x;
+        normalize3(nx, ny, nz);
+        h.nx = nx; h.ny = ny; h.nz = nz;
+        const float k2 = dot3(ray.dx, ray.dy, ray.dz, nx, ny, nz) * -2.0f;
+        h.rx = fma_<FUSED>(k2, nx, ray.dx);
+        h.ry = fma_<FUSED>(k2, ny, ray.dy);
+        h.rz = fma_<FUSED>(k2, nz, ray.dz);
+        h.index = index;
+        return;
+    }
     const float4 r0 = o->row0, r1 = o->row1, r2 = o->row2, r3 = c->inv_row3;
     const float sx = row4<FUSED>(r0.x, r0.y, r0.z, r0.w, ray.sx, ray.sy, ray.sz, ray.sw);
     const float sy = row4<FUSED>(r1.x, r1.y, r1.z, r1.w, ray.sx, ray.sy, ray.sz, ray.sw);

@@ -65,7 +65,16 @@ struct ScreenTiles {
     uint32_t enabled;
 };
 
-// order-free closest-hit update (see header comment); `cur_sphere` = the current winner is a sphere
+// order-free closest-hit update (see header comment); `cur_sphere` = the current winner is a sphere. Triangles
+// (extension) tie like boxes: the earlier object wins.
+__device__ __forceinline__ void closest_take(float t, int k, bool sphere, float& T, int& index, bool& cur_sphere) {
+    bool take;
+    if (t < T) take = true;
+    else if (t == T) take = sphere ? (!cur_sphere || k > index) : (!cur_sphere && k < index);
+    else take = false;
+    if (take) { T = t; index = k; cur_sphere = sphere; }
+}
+
 template <bool FUSED>
 __device__ __forceinline__ void closest_update_unordered(uint32_t type, float sx, float sy, float sz, float dx, float dy,
                                                          float dz, int k, float& T, int& index, bool& cur_sphere) {
@@ -73,13 +82,7 @@ __device__ __forceinline__ void closest_update_unordered(uint32_t type, float sx
     bool cand = false;
     if (type == 0u) cand = sphere_candidate<FUSED>(sx, sy, sz, dx, dy, dz, t);
     else if (type == 1u) cand = box_candidate(sx, sy, sz, dx, dy, dz, t);
-    if (!cand) return;
-    const bool sphere = (type == 0u);
-    bool take;
-    if (t < T) take = true;
-    else if (t == T) take = sphere ? (!cur_sphere || k > index) : (!cur_sphere && k < index);
-    else take = false;
-    if (take) { T = t; index = k; cur_sphere = sphere; }
+    if (cand) closest_take(t, k, type == 0u, T, index, cur_sphere);
 }
 
 // Cheap conservative rejection of a grid candidate before its 52-byte matrix is fetched. s = (centre, w): the
@@ -118,6 +121,24 @@ __device__ __forceinline__ void lane_object_space(const HotObject* __restrict__ 
         dy = row4<FUSED>(r1.x, r1.y, r1.z, r1.w, ray.dx, ray.dy, ray.dz, ray.dw);
         dz = row4<FUSED>(r2.x, r2.y, r2.z, r2.w, ray.dx, ray.dy, ray.dz, ray.dw);
     }
+}
+
+// the reference's exact test of one object (any type) for one lane: candidate or not, and its t
+template <bool FUSED, bool DW0>
+__device__ __forceinline__ bool lane_candidate(const HotObject* __restrict__ o, const Ray& ray, float& t, bool& sphere) {
+    const uint32_t type = o->type;
+    sphere = (type == 0u);
+    if (type == 2u) {
+        const float4 r0 = o->row0, r1 = o->row1, r2 = o->row2;
+        return triangle_candidate(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r2.x, r2.y, r2.z, r0.w, r1.w, r2.w,
+                                  __uint_as_float(o->pad[0]), ray, t);
+    }
+    float sx, sy, sz, dx, dy, dz;
+    uint32_t ty;
+    lane_object_space<FUSED, DW0>(o, ray, sx, sy, sz, dx, dy, dz, ty);
+    if (type == 0u) return sphere_candidate<FUSED>(sx, sy, sz, dx, dy, dz, t);
+    if (type == 1u) return box_candidate(sx, sy, sz, dx, dy, dz, t);
+    return false;
 }
 
 // 3-D DDA state for one ray. All of it is plain fp32 bookkeeping about WHICH cells to look at; it never feeds
@@ -252,10 +273,9 @@ __device__ __forceinline__ void closest_hit_grid(const GridDesc& g, const HotObj
     tested = g.n_always;
     for (uint32_t a = 0; a < g.n_always; ++a) {
         const int k = (int)g.always[a];
-        float sx, sy, sz, dx, dy, dz;
-        uint32_t type;
-        lane_object_space<FUSED, DW0>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
-        closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, k, T, index, cur_sphere);
+        float t;
+        bool sphere;
+        if (lane_candidate<FUSED, DW0>(hot + k, ray, t, sphere)) closest_take(t, k, sphere, T, index, cur_sphere);
     }
     Walk w = walk_begin(g, ray, 3.0e38f);
     if (!w.alive) return;
@@ -270,10 +290,9 @@ __device__ __forceinline__ void closest_hit_grid(const GridDesc& g, const HotObj
         tested += e1 - e0;
         for (uint32_t e = e0; e < e1; ++e) {
             const int k = (int)g.entries[e];
-            float sx, sy, sz, dx, dy, dz;
-            uint32_t type;
-            lane_object_space<FUSED, DW0>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
-            closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, k, T, index, cur_sphere);
+            float t;
+            bool sphere;
+            if (lane_candidate<FUSED, DW0>(hot + k, ray, t, sphere)) closest_take(t, k, sphere, T, index, cur_sphere);
         }
         if (!walk_next(g, w)) break;
         if (w.t_enter > T + slack) break;  // T is +MAX until something is hit

@@ -229,6 +229,22 @@ __global__ __launch_bounds__(256) void wf_trace_closest_grid(const WfParams w, u
     if (w.count_rays) atomicAdd(&w.rp.counters->tests, (unsigned long long)tested);
 }
 
+// one object of a wave-uniform list (scalar loads) against this lane's ray
+template <bool FUSED>
+__device__ __forceinline__ void tile_candidate(const RT_CONST HotObjectC* o, int k, const Ray& ray, float& T, int& idx, bool& cur_sphere) {
+    const uint32_t type = o->type;
+    if (type == 2u) {  // triangle (extension)
+        const f4 r0 = o->row0, r1 = o->row1, r2 = o->row2;
+        float t;
+        if (triangle_candidate(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r2.x, r2.y, r2.z, r0.w, r1.w, r2.w, __uint_as_float(o->pad[0]), ray, t))
+            closest_take(t, k, false, T, idx, cur_sphere);
+        return;
+    }
+    float sx, sy, sz, dx, dy, dz;
+    object_space_one<FUSED, true>(o, ray, sx, sy, sz, dx, dy, dz);
+    closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, k, T, idx, cur_sphere);
+}
+
 // First round of a pinhole frame: a wave holds 64 consecutive pixels of one row, i.e. one 64x8 screen tile, and
 // walks that tile's object list with wave-uniform scalar loads (plus the always-list). Waves that straddle tiles
 // (ragged ends) fall back to the per-lane grid walk. Order-free tie rules, so the result is the same either way.
@@ -256,17 +272,13 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams w, 
         const RT_CONST HotObjectC* hot = (const RT_CONST HotObjectC*)(p.scene.hot);
         for (uint32_t a = 0; a < w.grid.n_always; ++a) {
             const int k = (int)w.grid.always[a];
-            float sx, sy, sz, dx, dy, dz;
-            object_space_one<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz);
-            closest_update_unordered<FUSED>(hot[k].type, sx, sy, sz, dx, dy, dz, k, T, idx, cur_sphere);
+            tile_candidate<FUSED>(hot + k, k, ray, T, idx, cur_sphere);
         }
         const uint32_t e0 = w.tiles.tile_start[first], e1 = w.tiles.tile_start[first + 1];
         tested = w.grid.n_always + (e1 - e0);
         for (uint32_t e = e0; e < e1; ++e) {
             const int k = (int)w.tiles.entries[e];
-            float sx, sy, sz, dx, dy, dz;
-            object_space_one<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz);
-            closest_update_unordered<FUSED>(hot[k].type, sx, sy, sz, dx, dy, dz, k, T, idx, cur_sphere);
+            tile_candidate<FUSED>(hot + k, k, ray, T, idx, cur_sphere);
         }
     } else {
         closest_hit_grid<FUSED, true>(w.grid, p.scene.hot, ray, T, idx, tested);
@@ -368,12 +380,12 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 bool done = false;
                 for (uint32_t a = 0; a < g.n_always && !done; ++a) {  // objects every ray must test (usually none)
                     const int k = (int)g.always[a];
-                    float sx, sy, sz, dx, dy, dz;
-                    uint32_t type;
-                    lane_object_space<FUSED, true>(hot + k, ray, sx, sy, sz, dx, dy, dz, type);
+                    float t;
+                    bool sphere;
+                    const bool cand = lane_candidate<FUSED, true>(hot + k, ray, t, sphere);
                     if (STATS) ++tested;
-                    if (ANY) done = occludes<FUSED>(type, sx, sy, sz, dx, dy, dz);
-                    else closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, k, T, idx, cur_sphere);
+                    if (ANY) done = cand && t < 1.f;
+                    else if (cand) closest_take(t, k, sphere, T, idx, cur_sphere);
                 }
                 dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
                 slack = dd > 0.f ? kWalkSlackCells * g.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
@@ -432,16 +444,16 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 ((uint32_t)__popcll(stuck) << RT_DEFER_STUCK_SHIFT) >= n_live) {
                 if (STATS && lane == 0u) ++s_flush;
                 if (pend) {
-                    float sx, sy, sz, dx, dy, dz;
-                    uint32_t type;
                     const int pend_k = (int)g.entries[pend_e];
-                    lane_object_space<FUSED, true>(hot + pend_k, ray, sx, sy, sz, dx, dy, dz, type);
+                    float t;
+                    bool sphere;
+                    const bool cand = lane_candidate<FUSED, true>(hot + pend_k, ray, t, sphere);
                     if (STATS) ++tested;
                     pend = false;
                     if (ANY) {
-                        if (occludes<FUSED>(type, sx, sy, sz, dx, dy, dz)) { U(w, F_RES_ANY, pix) = 0u; st = 0; }
-                    } else {
-                        closest_update_unordered<FUSED>(type, sx, sy, sz, dx, dy, dz, pend_k, T, idx, cur_sphere);
+                        if (cand && t < 1.f) { U(w, F_RES_ANY, pix) = 0u; st = 0; }
+                    } else if (cand) {
+                        closest_take(t, pend_k, sphere, T, idx, cur_sphere);
                     }
                 }
             }

@@ -128,6 +128,49 @@ static inline void materialise(Hit* hit, const float* obj, const float* p, const
     memcpy(hit->mat, obj + OBJ_MAT, 64);
 }
 
+/* EXTENSION (no reference semantics; spec: DESIGN.md section 11): primitive type 2 = triangle.
+ * Record: `mv` columns 0,1,2 = the vertices v0,v1,v2 in VIEW space (w = 1), `mvInverse` column 0 = a guard
+ * sphere (cx, cy, cz, R) chosen by whoever builds the record; a ray is only tested against the triangle if its
+ * line passes that sphere - which makes every accepted hit local, so an acceleration structure can find it.
+ * Arithmetic: fp32, no contraction in either flavour, sums left to right, IEEE division:
+ *   guard:  oc = c - start; disc = (oc.d)^2 - (d.d) ((oc.oc) - R R); disc < 0 -> miss
+ *   Moeller-Trumbore, two-sided: e1 = v1 - v0, e2 = v2 - v0, p = d x e2, det = e1.p (0 or NaN -> miss),
+ *   inv = 1/det, tv = start - v0, u = (tv.p) inv in [0,1], q = tv x e1, v = (d.q) inv >= 0, u + v <= 1,
+ *   t = (e2.q) inv >= 0. Ties in t: the earlier object wins (like the box). Normal = normalize(e1 x e2). */
+static inline void cross3(float* o, const float* a, const float* b) {
+    o[0] = a[1] * b[2] - a[2] * b[1];
+    o[1] = a[2] * b[0] - a[0] * b[2];
+    o[2] = a[0] * b[1] - a[1] * b[0];
+}
+static inline float dot3p(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static int triangle_hit(const float* obj, const float* ray, float* t_out, float* normal_out) {
+    const float* v0 = obj + OBJ_MV;
+    const float* v1 = obj + OBJ_MV + 4;
+    const float* v2 = obj + OBJ_MV + 8;
+    const float* gs = obj + OBJ_MVINV;
+    const float* s = ray;
+    const float* d = ray + 4;
+    float oc[3], e1[3], e2[3], tv[3], p[3], q[3];
+    for (int i = 0; i < 3; ++i) { oc[i] = gs[i] - s[i]; e1[i] = v1[i] - v0[i]; e2[i] = v2[i] - v0[i]; tv[i] = s[i] - v0[i]; }
+    const float oo = dot3p(oc, oc), od = dot3p(oc, d), dd = dot3p(d, d);
+    const float disc = od * od - dd * (oo - gs[3] * gs[3]);
+    if (disc < 0) return 0;
+    cross3(p, d, e2);
+    const float det = dot3p(e1, p);
+    if (!(det != 0)) return 0;
+    const float inv = 1.0f / det;
+    const float u = dot3p(tv, p) * inv;
+    if (!(u >= 0 && u <= 1)) return 0;
+    cross3(q, tv, e1);
+    const float v = dot3p(d, q) * inv;
+    if (!(v >= 0 && u + v <= 1)) return 0;
+    const float t = dot3p(e2, q) * inv;
+    if (!(t >= 0)) return 0;
+    *t_out = t;
+    cross3(normal_out, e1, e2);
+    return 1;
+}
+
 /* raycast(): closest hit over all objects in ascending index order
  * (shade_and_reflect_kernel.cl:72-177; shade_kernel.cl:66-168; hittest_kernel.cl:63-147).
  * variant 2 = shade_and_reflect (reflection vector, `time == MAX` miss test),
@@ -135,11 +178,22 @@ static inline void materialise(Hit* hit, const float* obj, const float* p, const
 static int raycast(uint64_t count, const float* objs, const float* ray, Hit* hit, int variant) {
     for (uint64_t k = 0; k < count; ++k) {
         const float* obj = objs + k * OBJ_STRIDE;
+        uint32_t type;
+        memcpy(&type, obj + OBJ_TYPE, 4);
+        if (type == 2) { /* triangle (extension, see triangle_hit) */
+            float t, n[3];
+            if (!triangle_hit(obj, ray, &t, n)) continue;
+            if (hit->time <= t) continue; /* ties: the earlier object wins */
+            hit->time = t;
+            hit->index = (int)k;
+            for (int i = 0; i < 4; ++i) hit->inter[i] = FMA(t, ray[4 + i], ray[i]);
+            normalize3(hit->normal, n);
+            memcpy(hit->mat, obj + OBJ_MAT, 64);
+            continue;
+        }
         float s[4], d[4];
         xform4(s, obj + OBJ_MVINV, ray);
         xform4(d, obj + OBJ_MVINV, ray + 4);
-        uint32_t type;
-        memcpy(&type, obj + OBJ_TYPE, 4);
         if (type == 0) { /* unit sphere */
             float A = d[1] * d[1];
             A = FMA(d[0], d[0], A);
