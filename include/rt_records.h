@@ -36,7 +36,9 @@ typedef struct rt_object_data {
     float mv[16];
     float mvInverse[16];
     float mvInverseTranspose[16]; /* uploaded by the reference, read by no kernel */
-    uint32_t type;                /* 0 sphere, 1 box (ObjectData.hpp:9-12) */
+    uint32_t type;                /* 0 sphere, 1 box (ObjectData.hpp:9-12); 2 triangle - an EXTENSION of this backend with
+                                   * no reference semantics: mv columns 0..2 = vertices in view space
+                                   * (w = 1), mvInverse column 0 = guard sphere (cx, cy, cz, R); large-scene (grid) path only */
     uint8_t spacer[60];
 } rt_object_data;
 

@@ -608,7 +608,10 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     {
         const double max_ext = std::max(ext[0], std::max(ext[1], ext[2]));
         std::vector<uint64_t> keys;
-        for (int attempt = 0; attempt < 8 && max_ext / (cell * 0.7) < 280.0; ++attempt) {
+        const double vol = std::max(ext[0], 1e-6) * std::max(ext[1], 1e-6) * std::max(ext[2], 1e-6);
+        double max_dim = 280.0;
+        if (const char* env = std::getenv("RT_GRID_MAX_DIM")) max_dim = std::min(1000.0, std::max(16.0, std::atof(env)));
+        for (int attempt = 0; attempt < 10 && max_ext / (cell * 0.7) < max_dim && vol / std::pow(cell * 0.7, 3) < 128.0 * n; ++attempt) {
             keys.clear();
             keys.reserve(n);
             for (uint32_t i = 0; i < n; ++i) {
@@ -656,9 +659,15 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
         const double cl = std::sqrt(cc[0] * cc[0] + cc[1] * cc[1] + cc[2] * cc[2]);
         const double a2 = sph[i].r * sph[i].r * (1.0 + 2e-6);
         const double L = 2.2e-6 * kap * (S_max + cl) + 2e-6 * k2 * std::sqrt(D2);
-        const double reg = std::sqrt(a2 + 3e-6 * k2 * D2) + L;
+        double reg = std::sqrt(a2 + 3e-6 * k2 * D2) + L;
+        if (objs[i].type == 2u) {
+            // triangle: the guard |(c - start) x d|^2 <= R^2 |d|^2 is computed with an error of ~10 u R |c - start| |d|^2
+            // (cross-product form), i.e. it can pass lines up to R + ~5 u D away; + the rounding of c - start itself
+            reg = sph[i].r * (1.0 + 1e-6) + 2e-6 * std::sqrt(D2) + 1e-6 * (S_max + cl);
+        }
         rg[i] = reg * (1.0 + 1e-6) + 0.01 * cell;  // + slack for the kernels' fp32 cell arithmetic
-        if (k2 <= kKappa2Tight) { rpre[i] = std::sqrt(a2) + 2.0 * L + 1e-6 * cl; K2 = std::max(K2, k2); }
+        if (objs[i].type == 2u) rpre[i] = -(reg * (1.0 + 1e-6) + 1e-6 * cl);  // no distance term: its guard has none to speak of
+        else if (k2 <= kKappa2Tight) { rpre[i] = std::sqrt(a2) + 2.0 * L + 1e-6 * cl; K2 = std::max(K2, k2); }
         else rpre[i] = -(reg * (1.0 + 1e-6) + 1e-6 * cl);
         if (!std::isfinite(rg[i]) || rg[i] > 0.25 * diag) { rg[i] = inf; always.push_back(i); }  // as big as the scene: test it for every ray
     }
@@ -675,7 +684,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     for (int a = 0; a < 3; ++a) {
         dim[a] = (int)std::ceil((ghi[a] - glo[a]) / cell);
         if (dim[a] < 1) dim[a] = 1;
-        if (dim[a] > 320) return RT_OK;
+        if (dim[a] > 1040) return RT_OK;
     }
     const float cellf = (float)cell;
     const float lof[3] = {(float)glo[0], (float)glo[1], (float)glo[2]};

@@ -190,18 +190,18 @@ __device__ __forceinline__ bool box_line_misses(float sx, float sy, float sz, fl
     return ss < 1.0e5f && disc < 0.0f;
 }
 
-// EXTENSION, no reference semantics (spec: DESIGN.md section 11; CPU statement: oracle/rt_oracle.c triangle_hit):
+// EXTENSION, no reference semantics (spec: DESIGN.md section 11; the tests hold a CPU statement of it):
 // triangle with vertices in view space. fp32, no contraction in either flavour, sums left to right, IEEE division.
 // A ray is only tested if its line passes the record's guard sphere, which makes every accepted hit local.
 __device__ __forceinline__ bool triangle_candidate(float v0x, float v0y, float v0z, float e1x, float e1y, float e1z, float e2x,
                                                    float e2y, float e2z, float cx, float cy, float cz, float R, const Ray& ray,
                                                    float& t) {
     const float ocx = cx - ray.sx, ocy = cy - ray.sy, ocz = cz - ray.sz;
-    const float oo = ocx * ocx + ocy * ocy + ocz * ocz;
-    const float od = ocx * ray.dx + ocy * ray.dy + ocz * ray.dz;
+    const float gx = ocy * ray.dz - ocz * ray.dy;
+    const float gy = ocz * ray.dx - ocx * ray.dz;
+    const float gz = ocx * ray.dy - ocy * ray.dx;
     const float dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
-    const float disc = od * od - dd * (oo - R * R);
-    if (disc < 0) return false;
+    if (gx * gx + gy * gy + gz * gz > (R * R) * dd) return false;  // the line passes the guard sphere's centre further than R
     const float px = ray.dy * e2z - ray.dz * e2y;
     const float py = ray.dz * e2x - ray.dx * e2z;
     const float pz = ray.dx * e2y - ray.dy * e2x;

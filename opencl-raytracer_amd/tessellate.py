@@ -3,7 +3,7 @@ tessellated to ~1M triangles").
 
 EXTENSION - the reference has no triangle type, no tessellator and therefore no semantics to match
 (SURVEY.md 8d/8f5). The triangle record and its arithmetic are this repo's own spec (DESIGN.md section 11);
-parity for triangle scenes is self-parity: the HIP path against oracle/rt_oracle.c's statement of the same spec.
+parity for triangle scenes is self-parity: the HIP path against the tests' CPU statement of the same spec.
 
 Record (the reference's 320-byte ObjectData, `type = 2`):
   mv        columns 0,1,2 = vertices v0,v1,v2 in VIEW space (w = 1); column 3 = (0,0,0,1)

@@ -133,7 +133,8 @@ static inline void materialise(Hit* hit, const float* obj, const float* p, const
  * sphere (cx, cy, cz, R) chosen by whoever builds the record; a ray is only tested against the triangle if its
  * line passes that sphere - which makes every accepted hit local, so an acceleration structure can find it.
  * Arithmetic: fp32, no contraction in either flavour, sums left to right, IEEE division:
- *   guard:  oc = c - start; disc = (oc.d)^2 - (d.d) ((oc.oc) - R R); disc < 0 -> miss
+ *   guard:  oc = c - start; g = oc x d; (g.g) > (R R) (d.d) -> miss   (line further than R from c; the cross
+ *           product form keeps its rounding error ~1e-7 R |oc|, far below the discriminant form's ~1e-6 |oc|^2)
  *   Moeller-Trumbore, two-sided: e1 = v1 - v0, e2 = v2 - v0, p = d x e2, det = e1.p (0 or NaN -> miss),
  *   inv = 1/det, tv = start - v0, u = (tv.p) inv in [0,1], q = tv x e1, v = (d.q) inv >= 0, u + v <= 1,
  *   t = (e2.q) inv >= 0. Ties in t: the earlier object wins (like the box). Normal = normalize(e1 x e2). */
@@ -152,9 +153,9 @@ static int triangle_hit(const float* obj, const float* ray, float* t_out, float*
     const float* d = ray + 4;
     float oc[3], e1[3], e2[3], tv[3], p[3], q[3];
     for (int i = 0; i < 3; ++i) { oc[i] = gs[i] - s[i]; e1[i] = v1[i] - v0[i]; e2[i] = v2[i] - v0[i]; tv[i] = s[i] - v0[i]; }
-    const float oo = dot3p(oc, oc), od = dot3p(oc, d), dd = dot3p(d, d);
-    const float disc = od * od - dd * (oo - gs[3] * gs[3]);
-    if (disc < 0) return 0;
+    float g[3];
+    cross3(g, oc, d);
+    if (dot3p(g, g) > (gs[3] * gs[3]) * dot3p(d, d)) return 0;
     cross3(p, d, e2);
     const float det = dot3p(e1, p);
     if (!(det != 0)) return 0;

@@ -1,0 +1,118 @@
+"""Triangles (type 2, extension - DESIGN.md section 11) through the HIP path: SELF-parity against the oracle's
+statement of the same spec (there is no reference behaviour to match). Bars as for the other primitives: nearest t
+and hit index exact, reference-ray count equal, RGB within 1e-5."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from helpers import R, camera, compare_frames, rotation
+from opencl_raytracer_amd import scene_loader, tessellate as T
+
+pytestmark = pytest.mark.gpu
+RGB_ATOL = 1e-5
+SCENES = Path(__file__).resolve().parents[1] / "scenes"
+
+
+def hip(*a, **k):
+    from opencl_raytracer_amd.hip_raytracer import HIPRaytracer
+    return HIPRaytracer(*a, **k)
+
+
+def _check(objs, lights, rays, depth, o, kernels=("hittest", "shade", "shade_and_reflect")):
+    for kernel in kernels:
+        with hip(objs, lights, rays, depth, kernel=kernel) as rt:
+            got = rt.Render()
+            t, idx = rt.render_aux()
+            st = rt.count_rays()
+        want = o.render(kernel, objs, lights, rays, depth)
+        assert st.wavefront == 1
+        assert np.array_equal(t.view(np.uint32), want["hit_t"].view(np.uint32)), kernel
+        assert np.array_equal(idx, want["hit_index"]), kernel
+        assert st.rays_reference == want["rays_ref"], kernel
+        if kernel == "hittest":
+            assert np.array_equal(got.view(np.uint32), want["out"].view(np.uint32))
+        else:
+            assert compare_frames(got, want["out"]) <= RGB_ATOL, kernel
+    return want
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_tessellated_rounded_cube_vs_oracle(restatement, fused):
+    objs, lights = scene_loader.load_scene(str(SCENES / "roundedCube.txt"))
+    tri = T.tessellate(objs, 12, 24, 3)
+    rays = camera.primary_rays(160, 120)
+    for kernel in ("hittest", "shade_and_reflect"):
+        with hip(tri, lights, rays, 5, kernel=kernel, fused=fused) as rt:
+            got = rt.Render()
+            t, idx = rt.render_aux()
+        want = restatement[fused].render(kernel, tri, lights, rays, 5)
+        assert np.array_equal(idx, want["hit_index"]) and np.array_equal(t.view(np.uint32), want["hit_t"].view(np.uint32))
+        if kernel != "hittest":
+            assert compare_frames(got, want["out"]) <= RGB_ATOL
+    assert int((want["hit_index"] >= 0).sum()) > 2000
+
+
+def test_mixed_primitives_and_random_soup(restatement):
+    """Spheres, boxes and a soup of random (also sliver-thin and tiny) triangles in one scene, several lights,
+    reflective materials, rays from inside the cloud."""
+    rng = np.random.default_rng(31415)
+    from helpers import random_scene
+    objs, lights = random_scene(150, 100, 3, seed=77, spread=8.0, zrange=(-40.0, -8.0))
+    n = 4000
+    c = np.stack([rng.uniform(-9, 9, n), rng.uniform(-9, 9, n), rng.uniform(-42, -6, n)], axis=1)
+    size = rng.choice([0.02, 0.3, 1.5], size=n)[:, None]
+    v0 = c + rng.normal(size=(n, 3)) * size
+    v1 = c + rng.normal(size=(n, 3)) * size
+    v2 = np.where(rng.uniform(size=(n, 1)) < 0.2, v0 + (v1 - v0) * rng.uniform(size=(n, 1)) + rng.normal(size=(n, 3)) * 1e-4,   # slivers
+                  c + rng.normal(size=(n, 3)) * size)
+    tmpl = objs[0].copy()
+    tmpl["absorption"] = 0.4
+    soup = T.triangle_records(v0, v1, v2, tmpl)
+    for f in ("ambient", "diffuse", "specular"):
+        soup[f][:, :3] = rng.uniform(0.1, 0.9, size=(n, 3))
+    scene = np.concatenate([objs, soup])
+    scene = scene[rng.permutation(len(scene))]               # interleave the types (tie rules, pair stream)
+    rays = camera.primary_rays(128, 96)
+    want = _check(scene, lights, rays, 3, restatement[True])
+    hit_types = scene["type"][want["hit_index"][want["hit_index"] >= 0]]
+    assert {0, 1, 2} <= set(int(x) for x in np.unique(hit_types))
+
+
+def test_coplanar_duplicates_and_shared_edges_tie_like_the_oracle(restatement):
+    """Exact ties in t (duplicated triangles, rays through shared edges / vertices): the earlier record wins."""
+    tmpl = R.make_object(R.SPHERE, R.Material((.3, .3, .3), (.6, .6, .6), (.4, .4, .4), absorption=0.6, shininess=8), np.eye(4, dtype=np.float32))
+    quads = []
+    for i in range(12):
+        for j in range(12):
+            x, y = -3.0 + 0.5 * i, -3.0 + 0.5 * j
+            quads.append(((x, y, -9.0), (x + 0.5, y, -9.0), (x + 0.5, y + 0.5, -9.0)))
+            quads.append(((x, y, -9.0), (x + 0.5, y + 0.5, -9.0), (x, y + 0.5, -9.0)))
+    v = np.array(quads)
+    tri = T.triangle_records(v[:, 0], v[:, 1], v[:, 2], tmpl)
+    tri = np.concatenate([tri, tri[::3], tri[::5]])           # exact duplicates, later in the list
+    for k, rec in enumerate(tri):
+        tri["ambient"][k][:3] = ((k * 37 % 97) / 97.0, (k * 11 % 89) / 89.0, (k * 53 % 83) / 83.0)
+    lights = R.lights_array([R.make_light(R.LightProperties((.5, .5, .5), (.5, .5, .5), (.5, .5, .5)), position=(1, 2, 3, 1))])
+    # a ray grid whose directions land exactly on the mesh's vertices and edges (z = -9: x = 9 dx / 64 ...)
+    n = 25
+    rays = np.zeros(n * n, dtype=R.RAY_DTYPE)
+    xs = np.linspace(-3.0, 3.0, n)
+    rays["start"][:] = (0, 0, 0, 1)
+    rays["direction"][:, 0] = np.repeat(xs, n)
+    rays["direction"][:, 1] = np.tile(xs, n)
+    rays["direction"][:, 2] = -9.0
+    _check(tri, lights, rays, 2, restatement[True])
+
+
+def test_triangles_need_the_grid_path():
+    tmpl = R.make_object(R.SPHERE, R.Material((.3, .3, .3)), np.eye(4, dtype=np.float32))
+    tri = T.triangle_records([(0, 0, -5)], [(1, 0, -5)], [(0, 1, -5)], tmpl)
+    lights = R.lights_array([R.make_light(R.LightProperties((1, 1, 1)), position=(0, 0, 5, 1))])
+    rays = camera.primary_rays(8, 8)
+    for kw in ({"literal": True}, {"grid": False}, {"path": "monolithic"}):
+        with pytest.raises(Exception, match="triangle"):
+            hip(tri, lights, rays, 1, **kw)
+    with hip(tri, lights, rays, 1) as rt:                     # one triangle: still the grid path
+        rt.Render()
+        assert rt.stats().wavefront == 1
