@@ -772,6 +772,10 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     g.entry_sphere = c->d_grid_entry_sphere;
     g.always = c->d_grid_always;
     g.n_always = (uint32_t)always.size();
+    g.has_triangles = c->has_triangles ? 1u : 0u;
+    g.nan_winner = -1;
+    for (uint32_t i = n; i-- > 0;)
+        if (objs[i].type <= 1u) { g.nan_winner = (int)i; break; }
     g.pretest_alpha = std::nextafter((float)(6e-6 * K2 + 8e-6), std::numeric_limits<float>::infinity());
     g.enabled = 1u;
     c->h_grid_spheres.resize(4 * (size_t)n);

@@ -54,6 +54,9 @@ struct GridDesc {
     const uint32_t* __restrict__ always;      // objects every ray must test
     uint32_t n_always;
     float pretest_alpha;   // distance-dependent term of the pre-test radius (misses_bounding_sphere)
+    uint32_t has_triangles;  // the scene holds type-2 records (selects the kernel variants that know them)
+    int nan_winner;        // what the reference's loop returns for a NaN ray: every sphere / box "accepts" it with
+                           // t = NaN (all its rejections are comparisons), so the LAST one wins; -1: none in the scene
     uint32_t enabled;
 };
 
@@ -124,11 +127,11 @@ __device__ __forceinline__ void lane_object_space(const HotObject* __restrict__ 
 }
 
 // the reference's exact test of one object (any type) for one lane: candidate or not, and its t
-template <bool FUSED, bool DW0>
+template <bool FUSED, bool DW0, bool TRI = true>
 __device__ __forceinline__ bool lane_candidate(const HotObject* __restrict__ o, const Ray& ray, float& t, bool& sphere) {
     const uint32_t type = o->type;
     sphere = (type == 0u);
-    if (type == 2u) {
+    if (TRI && type == 2u) {  // TRI = false: the caller knows the scene holds no triangles (saves registers in the walk)
         const float4 r0 = o->row0, r1 = o->row1, r2 = o->row2;
         return triangle_candidate(r0.x, r0.y, r0.z, r1.x, r1.y, r1.z, r2.x, r2.y, r2.z, r0.w, r1.w, r2.w,
                                   __uint_as_float(o->pad[0]), ray, t);
@@ -139,6 +142,16 @@ __device__ __forceinline__ bool lane_candidate(const HotObject* __restrict__ o, 
     if (type == 0u) return sphere_candidate<FUSED>(sx, sy, sz, dx, dy, dz, t);
     if (type == 1u) return box_candidate(sx, sy, sz, dx, dy, dz, t);
     return false;
+}
+
+// A ray with a NaN in it (and no infinity, which would make the outcome depend on the object) walks no cells; the
+// consumer of the result patches in what the reference's loop returns for it (closest_result, rt_wavefront.hip).
+// Shadow rays: NaN < 1 is false, nothing occludes - which is what the walk reports for a ray that misses the grid.
+__device__ __forceinline__ bool ray_has_nan(const Ray& ray) {
+    const float s = ((ray.sx + ray.sy) + ray.sz) + ((ray.dx + ray.dy) + ray.dz);
+    return !(s == s) && !(__builtin_fabsf(ray.sx) == __builtin_inff() || __builtin_fabsf(ray.sy) == __builtin_inff() ||
+                          __builtin_fabsf(ray.sz) == __builtin_inff() || __builtin_fabsf(ray.dx) == __builtin_inff() ||
+                          __builtin_fabsf(ray.dy) == __builtin_inff() || __builtin_fabsf(ray.dz) == __builtin_inff());
 }
 
 // 3-D DDA state for one ray. All of it is plain fp32 bookkeeping about WHICH cells to look at; it never feeds
@@ -162,6 +175,10 @@ __device__ __forceinline__ Walk walk_begin(const GridDesc& g, const Ray& ray, fl
     // secondary rays have w = 1, pinhole primaries too; other values are handled by the caller)
     const float ox = ray.sx, oy = ray.sy, oz = ray.sz;
     const float dx = ray.dx, dy = ray.dy, dz = ray.dz;
+    {   // NaN anywhere: no walk (fmin / fmax below would swallow it); callers give such rays the reference's result
+        const float chk = ((ox + oy) + oz) + ((dx + dy) + dz);
+        if (!(chk == chk)) return w;
+    }
     const float hix = g.lox + g.cell * (float)g.nx, hiy = g.loy + g.cell * (float)g.ny, hiz = g.loz + g.cell * (float)g.nz;
     // slab clip against the grid box, [t0, t1] subset of [0, t_limit]
     float t0 = 0.f, t1 = t_limit;

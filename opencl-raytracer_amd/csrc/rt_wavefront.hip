@@ -318,7 +318,7 @@ constexpr uint32_t kSegment = RT_SEGMENT;
 // instructions - runs for the whole wave when enough lanes hold one (or are stuck behind theirs), so it executes
 // with tens of lanes instead of the 3-5 that happen to need it in any single trip. The closest-hit update is
 // order-free and T only ever shrinks, so a late update can only make a lane look at MORE cells than necessary.
-template <bool FUSED, bool ANY, bool STATS>
+template <bool FUSED, bool ANY, bool STATS, bool TRI>
 __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue,
                                               uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr,
                                               unsigned long long& tested) {
@@ -382,7 +382,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                     const int k = (int)g.always[a];
                     float t;
                     bool sphere;
-                    const bool cand = lane_candidate<FUSED, true>(hot + k, ray, t, sphere);
+                    const bool cand = lane_candidate<FUSED, true, TRI>(hot + k, ray, t, sphere);
                     if (STATS) ++tested;
                     if (ANY) done = cand && t < 1.f;
                     else if (cand) closest_take(t, k, sphere, T, idx, cur_sphere);
@@ -447,7 +447,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                     const int pend_k = (int)g.entries[pend_e];
                     float t;
                     bool sphere;
-                    const bool cand = lane_candidate<FUSED, true>(hot + pend_k, ray, t, sphere);
+                    const bool cand = lane_candidate<FUSED, true, TRI>(hot + pend_k, ray, t, sphere);
                     if (STATS) ++tested;
                     pend = false;
                     if (ANY) {
@@ -477,13 +477,13 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 6
 #endif
-template <bool FUSED, bool ANY, bool STATS>
+template <bool FUSED, bool ANY, bool STATS, bool TRI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU))) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue,
                                                                  uint32_t* __restrict__ run_ctr) {
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * 256u) >> 6;
     unsigned long long tested = 0;
-    trace_segment<FUSED, ANY, STATS>(w, queue, n_queue, wave, n_waves, run_ctr, tested);
+    trace_segment<FUSED, ANY, STATS, TRI>(w, queue, n_queue, wave, n_waves, run_ctr, tested);
     if (STATS && tested) atomicAdd(&w.rp.counters->tests, tested);
 }
 
@@ -533,6 +533,20 @@ __global__ __launch_bounds__(256) void wf_trace_any_slice(const WfParams w, cons
 }
 
 // ---- the resumable pixel -------------------------------------------------------------------------------------------
+// Closest-hit result of pixel i. A ray with a NaN in it walks no cells (walk_begin) and comes back as a miss; the
+// reference's loop gives such a ray t = NaN on the LAST sphere / box of the scene, because every rejection in its
+// tests is a comparison that NaN fails. In practice these are reflections off a box hit whose object-space point
+// has no coordinate beyond 0.4998 (tiny far boxes: 0/0 normal). The brute-force kernels reproduce that by
+// construction; for the grid path it is patched in here, where the result is consumed.
+__device__ __forceinline__ void closest_result(const WfParams& w, uint64_t i, float& T, int& idx) {
+    T = F(w, F_RES_T, i);
+    idx = (int)U(w, F_RES_I, i);
+    if (T == kMaxFloat && w.grid.enabled && !w.rp.scene.literal && w.grid.nan_winner >= 0) {
+        const Ray ray = load_ray(w, i, kSlotClosest);
+        if (ray_has_nan(ray)) { T = __builtin_nanf(""); idx = w.grid.nan_winner; }
+    }
+}
+
 struct Ctx {
     const WfParams& w;
     uint64_t i;
@@ -717,9 +731,10 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
         // the ray left together with this hit's first shadow ray (begin_shade_lit) and has been traced: carry on
         // with its result, as the PH_REFLECT branch of wf_resume does one round later in the other modes
         const uint64_t i = c.i;
-        const float T = F(c.w, F_RES_T, i);
+        float T;
+        int idx;
+        closest_result(c.w, i, T, idx);
         if (T == kMaxFloat) { finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces); return; }
-        const int idx = (int)U(c.w, F_RES_I, i);
         const Ray ray = load_ray(c.w, i, kSlotClosest);
         HitRec rh;
         materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
@@ -772,8 +787,9 @@ __global__ __launch_bounds__(kResumeThreads) void wf_resume(const WfParams w) {
         const bool duplicate = (t < w.n_prev_closest) && (phase == PH_SHADOW_PRIMARY || phase == PH_SHADOW_REFLECT);
         if (duplicate) {
         } else if (phase == PH_PRIMARY) {
-            const float T = F(w, F_RES_T, i);
-            const int idx = (int)U(w, F_RES_I, i);
+            float T;
+            int idx;
+            closest_result(w, i, T, idx);
             const bool hit = (KERNEL == 2) ? !(T == kMaxFloat) : (T < kMaxFloat);
             c.traced += 1; c.reference += 1; c.hits += hit ? 1 : 0;
             if (w.rp.aux_t) w.rp.aux_t[pixel_of(w.rp, i)] = T;
@@ -794,8 +810,9 @@ __global__ __launch_bounds__(kResumeThreads) void wf_resume(const WfParams w) {
         } else if (phase == PH_SHADOW_REFLECT) {
             resume_shadow<KERNEL, FUSED>(c, false);
         } else if (phase == PH_REFLECT) {
-            const float T = F(w, F_RES_T, i);
-            const int idx = (int)U(w, F_RES_I, i);
+            float T;
+            int idx;
+            closest_result(w, i, T, idx);
             const float ap = F(w, F_AP, i);
             const uint32_t bounces = U(w, F_BOUNCES, i);
             const float abr = F(w, F_ABR, i), abg = F(w, F_ABG, i), abb = F(w, F_ABB, i);
@@ -839,6 +856,20 @@ static inline dim3 persistent_grid(uint64_t n) {
 size_t wavefront_state_bytes(uint64_t n_local) { return (size_t)F_COUNT * sizeof(float) * (size_t)n_local; }
 size_t wavefront_queue_bytes(uint64_t n_local) { return sizeof(uint32_t) * (size_t)n_local; }
 
+// one launch of the persistent grid walk (the template arguments pick the compiled variant)
+template <bool FUSED, bool ANY>
+static void launch_persistent(const WfParams& w, const uint32_t* queue, uint32_t n, uint32_t* ticket, hipStream_t s) {
+    const dim3 grid = persistent_grid(n), block(256);
+    const bool tri = w.grid.has_triangles != 0u;
+    if (w.count_rays) {
+        if (tri) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, true, true>), grid, block, 0, s, w, queue, n, ticket);
+        else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, true, false>), grid, block, 0, s, w, queue, n, ticket);
+    } else {
+        if (tri) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, false, true>), grid, block, 0, s, w, queue, n, ticket);
+        else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, false, false>), grid, block, 0, s, w, queue, n, ticket);
+    }
+}
+
 template <int KERNEL, bool FUSED>
 static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t stream, uint32_t* rounds_out) {
     hipError_t e;
@@ -881,8 +912,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
             any_stream = buf.side_stream;
             if ((e = hipEventRecord(buf.ev_fork, stream)) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(any_stream, buf.ev_fork, 0)) != hipSuccess) return e;
-            if (w.count_rays) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, true, true>), persistent_grid(na), dim3(256), 0, any_stream, w, (const uint32_t*)w.q_prev_any, na, buf.counts + 5);
-            else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, true, false>), persistent_grid(na), dim3(256), 0, any_stream, w, (const uint32_t*)w.q_prev_any, na, buf.counts + 5);
+            launch_persistent<FUSED, true>(w, w.q_prev_any, na, buf.counts + 5, any_stream);
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if ((e = hipEventRecord(buf.ev_join, any_stream)) != hipSuccess) return e;
         }
@@ -891,8 +921,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
                 hipLaunchKernelGGL((wf_trace_primary_tiles<FUSED>), grid_for(nc), dim3(256), 0, stream, w, nc);
             } else if (use_grid) {
                 if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest_grid<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
-                else if (w.count_rays) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, false, true>), persistent_grid(nc), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_closest, nc, buf.counts + 4);
-                else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, false, false>), persistent_grid(nc), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_closest, nc, buf.counts + 4);
+                else launch_persistent<FUSED, false>(w, w.q_prev_closest, nc, buf.counts + 4, stream);
             } else {
                 if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
                 else hipLaunchKernelGGL((wf_trace_closest<FUSED, true>), grid_for(nc), dim3(256), 0, stream, w, nc);
@@ -906,8 +935,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
                 hipLaunchKernelGGL((wf_trace_any_literal<FUSED>), grid_for(na), dim3(256), 0, stream, w, na);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             } else if (use_grid) {
-                if (w.count_rays) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, true, true>), persistent_grid(na), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_any, na, buf.counts + 5);
-                else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, true, false>), persistent_grid(na), dim3(256), 0, stream, w, (const uint32_t*)w.q_prev_any, na, buf.counts + 5);
+                launch_persistent<FUSED, true>(w, w.q_prev_any, na, buf.counts + 5, stream);
                 if ((e = hipGetLastError()) != hipSuccess) return e;
             } else {
                 // slices of >= kMinSlicePairs pairs (amortises each launch's pipeline fill), at most kMaxSlices
