@@ -671,7 +671,9 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
         else rpre[i] = -(reg * (1.0 + 1e-6) + 1e-6 * cl);
         if (!std::isfinite(rg[i]) || rg[i] > 0.25 * diag) { rg[i] = inf; always.push_back(i); }  // as big as the scene: test it for every ray
     }
-    if (always.size() > 64) return RT_OK;  // a grid would not pay: stay with the brute-force stream
+    // many scene-sized objects: a grid would not pay, stay with the brute-force stream - unless the scene holds
+    // triangles, which only this path can trace (then every ray simply tests the whole always-list)
+    if (always.size() > 64 && !c->has_triangles) return RT_OK;
     // the grid box: everything registered plus the ray origins, padded by one cell
     double glo[3], ghi[3];
     for (int a = 0; a < 3; ++a) { glo[a] = lo[a] - cell; ghi[a] = hi[a] + cell; }
@@ -737,7 +739,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
         if (pass == 0) {
             for (size_t k = 0; k < n_cells; ++k) start[k + 1] += start[k];
             total = start[n_cells];
-            if (total > 64ull * n + 1024) return RT_OK;  // objects too large for this cell size: not worth it
+            if (total > (c->has_triangles ? 1024ull : 64ull) * n + 1024) return RT_OK;  // objects too large for this cell size: not worth it
         } else {
             RT_HIP(c, hipMalloc((void**)&c->d_grid_entries, sizeof(uint32_t) * (total + 1)));
             RT_HIP(c, hipMalloc((void**)&c->d_grid_always, sizeof(uint32_t) * (always.size() + 1)));

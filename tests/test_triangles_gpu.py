@@ -116,3 +116,30 @@ def test_triangles_need_the_grid_path():
     with hip(tri, lights, rays, 1) as rt:                     # one triangle: still the grid path
         rt.Render()
         assert rt.stats().wavefront == 1
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_triangle_soup_fuzz_vs_oracle(restatement, seed):
+    """Random soups far from the origin, tiny to huge triangles, rays from everywhere: the grid path against the
+    CPU statement (which tests every triangle for every ray)."""
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.choice([200, 1500]))
+    spread = float(rng.choice([3.0, 40.0]))
+    far = float(rng.choice([0.0, 60.0, 1000.0]))
+    base = rng.normal(size=3)
+    base = base / np.linalg.norm(base) * far
+    size = rng.choice([0.01, 0.2, 2.0], size=n)[:, None] * spread / 3.0
+    c = base + rng.uniform(-spread, spread, (n, 3))
+    v0, v1, v2 = (c + rng.normal(size=(n, 3)) * size for _ in range(3))
+    tmpl = R.make_object(R.SPHERE, R.Material((.2, .3, .4), (.5, .5, .5), (.3, .3, .3), absorption=0.5, shininess=5), np.eye(4, dtype=np.float32))
+    tri = T.triangle_records(v0, v1, v2, tmpl)
+    lights = R.lights_array([R.make_light(R.LightProperties((.2, .2, .2), (.5, .5, .5), (.5, .5, .5)),
+                                          position=(*(base + rng.uniform(-spread, spread, 3) * 1.5), 1.0))])
+    m = 2048
+    rays = np.zeros(m, dtype=R.RAY_DTYPE)
+    rays["start"][:, :3] = base + rng.uniform(-spread, spread, (m, 3)) * 1.5
+    k = rng.integers(0, n, m)
+    rays["direction"][:, :3] = ((c[k] + rng.normal(size=(m, 3)) * size[k] * 0.5) - rays["start"][:, :3]) * rng.choice([0.05, 1.0, 30.0], size=(m, 1))
+    rays["start"][:, 3] = 1.0
+    want = _check(tri, lights, rays, 2, restatement[True], kernels=("hittest", "shade_and_reflect"))
+    assert int((want["hit_index"] >= 0).sum()) > m // 10
