@@ -475,10 +475,13 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
 }
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 6
+#define RT_WAVES_PER_EU 6      // <= 80 VGPRs: fits without spills when the triangle branch is compiled out
+#endif
+#ifndef RT_WAVES_PER_EU_TRI
+#define RT_WAVES_PER_EU_TRI 6  // the variants that know triangles would like ~90 VGPRs; 5 waves without spills measured slower (97.6 vs 93 ms, cfg5)
 #endif
 template <bool FUSED, bool ANY, bool STATS, bool TRI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU))) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRI ? RT_WAVES_PER_EU_TRI : RT_WAVES_PER_EU))) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue,
                                                                  uint32_t* __restrict__ run_ctr) {
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * 256u) >> 6;
