@@ -576,7 +576,10 @@ int build_screen_tiles(rt_context* c, hipStream_t stream) {
 // Conservative uniform grid for the large-scene trace kernels (rt_grid.h explains the margins).
 int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     c->grid = rt::GridDesc{};
-    if (n == 0 || (c->flags & RT_FLAG_NO_GRID) || !c->affine_w || !c->primary_w_one) return RT_OK;
+    // The grid reasons about ONE line in view space per ray. That needs w = 1 starts, affine instances (checked at
+    // upload) and direction.w = 0: with a non-zero direction.w the reference adds every object's own translation
+    // column to the object-space direction, i.e. each object sees a different line (found by the differential fuzz).
+    if (n == 0 || (c->flags & RT_FLAG_NO_GRID) || !c->affine_w || !c->primary_w_one || !(c->pinhole || c->dir_w_zero)) return RT_OK;
     std::vector<Bound> sph(n);
     double lo[3] = {c->origin_lo[0], c->origin_lo[1], c->origin_lo[2]};
     double hi[3] = {c->origin_hi[0], c->origin_hi[1], c->origin_hi[2]};

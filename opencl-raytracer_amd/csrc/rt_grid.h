@@ -316,4 +316,34 @@ __device__ __forceinline__ void closest_hit_grid(const GridDesc& g, const HotObj
     }
 }
 
+// Any hit with t < 1 through the grid, one thread per ray (the tail of a frame: wf_finish). Same answer as the
+// brute-force any-hit loops: every candidate that can occlude is registered in a cell the walk visits.
+template <bool FUSED>
+__device__ __forceinline__ bool any_hit_grid(const GridDesc& g, const HotObject* __restrict__ hot, const Ray& ray, uint32_t& tested) {
+    for (uint32_t a = 0; a < g.n_always; ++a) {
+        float t;
+        bool sphere;
+        ++tested;
+        if (lane_candidate<FUSED, true>(hot + (int)g.always[a], ray, t, sphere) && t < 1.f) return true;
+    }
+    const float len = __builtin_sqrtf(ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz);
+    const float slack = len > 0.f ? kWalkSlackCells * g.cell / len : 3.0e38f;
+    Walk w = walk_begin(g, ray, 1.0f + slack);
+    if (!w.alive) return false;
+    for (;;) {
+        const uint32_t c = ((uint32_t)w.iz * (uint32_t)g.ny + (uint32_t)w.iy) * (uint32_t)g.nx + (uint32_t)w.ix;
+        const uint2 range = g.cell_range[c];
+        tested += range.y;
+        for (uint32_t e = range.x; e < range.x + range.y; ++e) {
+            float t;
+            bool sphere;
+            if (lane_candidate<FUSED, true>(hot + (int)g.entries[e], ray, t, sphere) && t < 1.f) return true;
+        }
+        if (!walk_next(g, w)) break;
+        if (w.t_enter > 1.0f + slack) break;
+    }
+    return false;
+}
+
 }  // namespace rt
+

@@ -19,6 +19,7 @@
 #include "rt_kernels.h"
 #include "rt_grid.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -42,6 +43,8 @@ enum : uint32_t { PH_DONE = 0, PH_PRIMARY = 1, PH_SHADOW_PRIMARY = 2, PH_SHADOW_
 // flag on the phase word: the reflection ray that leaves the hit being shaded is already in flight / traced (its ray
 // in slot 0, its result in F_RES_T / F_RES_I) - see begin_shade
 constexpr uint32_t PH_FLAG_REFLECTION_SENT = 0x100u;
+// ... and it has not been traced yet (set for exactly the round that follows its emission; wf_finish needs to know)
+constexpr uint32_t PH_FLAG_REFLECTION_PENDING = 0x200u;
 
 struct WfParams {
     RenderParams rp;
@@ -209,24 +212,6 @@ __global__ __launch_bounds__(256) void wf_trace_closest(const WfParams w, uint32
     const unsigned long long lanes = (unsigned long long)__popcll(__ballot(true));
     if (w.count_rays && (threadIdx.x & 63u) == 0u)  // 2 tests per pair for every ray of the wave
         atomicAdd(&w.rp.counters->tests, 2ull * w.rp.scene.n_pairs * lanes);
-}
-
-// Closest hit through the conservative grid (rt_grid.h), one thread = one ray: identical results, a few dozen
-// candidate tests per ray instead of one per object. Used for first-round rays that are not a pinhole grid
-// (direction.w may be non-zero); every other ray goes through wf_trace_grid_persistent below.
-template <bool FUSED, bool DW0>
-__global__ __launch_bounds__(256) void wf_trace_closest_grid(const WfParams w, uint32_t n_queue) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n_queue) return;
-    const uint64_t i = w.q_prev_closest[t];
-    const Ray ray = load_ray(w, i, kSlotClosest);
-    float T = kMaxFloat;
-    int idx = -1;
-    uint32_t tested = 0;
-    closest_hit_grid<FUSED, DW0>(w.grid, w.rp.scene.hot, ray, T, idx, tested);
-    F(w, F_RES_T, i) = T;
-    U(w, F_RES_I, i) = (uint32_t)idx;
-    if (w.count_rays) atomicAdd(&w.rp.counters->tests, (unsigned long long)tested);
 }
 
 // one object of a wave-uniform list (scalar loads) against this lane's ray
@@ -602,7 +587,7 @@ __device__ __forceinline__ void begin_shade_lit(Ctx& c, const HitRec& h, bool pr
         store_ray(c.w, c.i, ray, kSlotClosest);
         c.want_closest = true;
         c.traced += 1;
-        flag = PH_FLAG_REFLECTION_SENT;
+        flag = PH_FLAG_REFLECTION_SENT | PH_FLAG_REFLECTION_PENDING;
     }
     const bool forward = (KERNEL == 1) || S.literal;
     // the carried light-loop terms start at zero: resume_shadow() knows the first light of a scan and does not
@@ -635,7 +620,8 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
     const LightRec L = S.lights[li];
     LightGeom g;
     light_geometry<FUSED>(L, h, nvx, nvy, nvz, vvx, vvy, vvz, g);
-    const uint32_t phase = (primary ? PH_SHADOW_PRIMARY : PH_SHADOW_REFLECT) | c.flags;
+    // (by the time a shadow result is resumed, a reflection ray sent with the hit's first shadow ray has been traced)
+    const uint32_t phase = (primary ? PH_SHADOW_PRIMARY : PH_SHADOW_REFLECT) | (c.flags & ~PH_FLAG_REFLECTION_PENDING);
     const bool forward = (KERNEL == 1) || S.literal;
     const bool first_of_scan = forward ? (li == 0u) : (li == S.n_lights - 1u);  // carried terms are still all zero
     float sr = 0.f, sg = 0.f, sb = 0.f;
@@ -774,70 +760,127 @@ __device__ void shade_done(Ctx& c, const HitRec& h, bool primary, float cr, floa
     }
 }
 
+// one step of a pixel's state machine: consume the results of the ray(s) it had in flight, queue what it needs next
+template <int KERNEL, bool FUSED>
+__device__ __forceinline__ void resume_pixel(Ctx& c) {
+    const WfParams& w = c.w;
+    const uint64_t i = c.i;
+    const Scene& S = w.rp.scene;
+    const uint32_t word = U(w, F_PHASE, i);
+    const uint32_t phase = word & 0xffu;
+    c.flags = word & ~0xffu;
+    if (phase == PH_PRIMARY) {
+        float T;
+        int idx;
+        closest_result(w, i, T, idx);
+        const bool hit = (KERNEL == 2) ? !(T == kMaxFloat) : (T < kMaxFloat);
+        c.traced += 1; c.reference += 1; c.hits += hit ? 1 : 0;
+        if (w.rp.aux_t) w.rp.aux_t[pixel_of(w.rp, i)] = T;
+        if (w.rp.aux_index) w.rp.aux_index[pixel_of(w.rp, i)] = hit ? idx : -1;
+        if (KERNEL == 0) {
+            reinterpret_cast<float*>(w.rp.out)[pixel_of(w.rp, i)] = hit ? T : kMaxFloat;
+            U(w, F_PHASE, i) = PH_DONE;
+        } else if (!hit) {
+            write_pixel<KERNEL>(c, 0.f, 0.f, 0.f);
+        } else {
+            const Ray ray = load_ray(w, i, kSlotClosest);
+            HitRec h;
+            materialise<FUSED>(S.hot, S.cold, idx, T, ray, h);
+            begin_shade<KERNEL, FUSED>(c, h, true, w.rp.max_bounces, S.cold[h.index].amb_absorb.w);
+        }
+    } else if (phase == PH_SHADOW_PRIMARY) {
+        resume_shadow<KERNEL, FUSED>(c, true);
+    } else if (phase == PH_SHADOW_REFLECT) {
+        resume_shadow<KERNEL, FUSED>(c, false);
+    } else if (phase == PH_REFLECT) {
+        float T;
+        int idx;
+        closest_result(w, i, T, idx);
+        const float ap = F(w, F_AP, i);
+        const uint32_t bounces = U(w, F_BOUNCES, i);
+        const float abr = F(w, F_ABR, i), abg = F(w, F_ABG, i), abb = F(w, F_ABB, i);
+        const float rr = F(w, F_RR, i), rg = F(w, F_RG, i), rb = F(w, F_RB, i);
+        if (T == kMaxFloat || !(ap <= 0.999f)) {  // raycast() false, or the absorption test of the loop condition
+            finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces);
+        } else {
+            const Ray ray = load_ray(w, i, kSlotClosest);
+            HitRec rh;
+            materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
+            begin_shade<KERNEL, FUSED>(c, rh, false, bounces, ap + (1.f - ap) * S.cold[rh.index].amb_absorb.w);
+        }
+    }
+}
+
+// a pixel with a shadow AND a reflection ray in flight sits in both queues: it is resumed from its shadow entry
+__device__ __forceinline__ bool duplicate_entry(const WfParams& w, uint32_t t, uint64_t i) {
+    const uint32_t phase = U(w, F_PHASE, i) & 0xffu;
+    return (t < w.n_prev_closest) && (phase == PH_SHADOW_PRIMARY || phase == PH_SHADOW_REFLECT);
+}
+
+__device__ __forceinline__ void add_ray_counters(const WfParams& w, const Ctx& c) {
+    const unsigned long long a = wave_sum64(c.traced), b = wave_sum64(c.reference), h = wave_sum64(c.hits);
+    if ((threadIdx.x & 63u) == 0u && (a | b | h)) {
+        atomicAdd(&w.rp.counters->traced, a);
+        atomicAdd(&w.rp.counters->reference, b);
+        atomicAdd(&w.rp.counters->hits, h);
+    }
+}
+
 template <int KERNEL, bool FUSED>
 __global__ __launch_bounds__(kResumeThreads) void wf_resume(const WfParams w) {
     const uint32_t t = blockIdx.x * kResumeThreads + threadIdx.x;
     const uint32_t total = w.n_prev_closest + w.n_prev_any;
     Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u};
     if (t < total) {
-        const uint64_t i = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
-        c.i = i;
-        const Scene& S = w.rp.scene;
-        const uint32_t word = U(w, F_PHASE, i);
-        const uint32_t phase = word & 0xffu;
-        c.flags = word & ~0xffu;
-        // a pixel with a shadow AND a reflection ray in flight sits in both queues: it is resumed from its shadow entry
-        const bool duplicate = (t < w.n_prev_closest) && (phase == PH_SHADOW_PRIMARY || phase == PH_SHADOW_REFLECT);
-        if (duplicate) {
-        } else if (phase == PH_PRIMARY) {
-            float T;
-            int idx;
-            closest_result(w, i, T, idx);
-            const bool hit = (KERNEL == 2) ? !(T == kMaxFloat) : (T < kMaxFloat);
-            c.traced += 1; c.reference += 1; c.hits += hit ? 1 : 0;
-            if (w.rp.aux_t) w.rp.aux_t[pixel_of(w.rp, i)] = T;
-            if (w.rp.aux_index) w.rp.aux_index[pixel_of(w.rp, i)] = hit ? idx : -1;
-            if (KERNEL == 0) {
-                reinterpret_cast<float*>(w.rp.out)[pixel_of(w.rp, i)] = hit ? T : kMaxFloat;
-                U(w, F_PHASE, i) = PH_DONE;
-            } else if (!hit) {
-                write_pixel<KERNEL>(c, 0.f, 0.f, 0.f);
-            } else {
-                const Ray ray = load_ray(w, i, kSlotClosest);
-                HitRec h;
-                materialise<FUSED>(S.hot, S.cold, idx, T, ray, h);
-                begin_shade<KERNEL, FUSED>(c, h, true, w.rp.max_bounces, S.cold[h.index].amb_absorb.w);
-            }
-        } else if (phase == PH_SHADOW_PRIMARY) {
-            resume_shadow<KERNEL, FUSED>(c, true);
-        } else if (phase == PH_SHADOW_REFLECT) {
-            resume_shadow<KERNEL, FUSED>(c, false);
-        } else if (phase == PH_REFLECT) {
-            float T;
-            int idx;
-            closest_result(w, i, T, idx);
-            const float ap = F(w, F_AP, i);
-            const uint32_t bounces = U(w, F_BOUNCES, i);
-            const float abr = F(w, F_ABR, i), abg = F(w, F_ABG, i), abb = F(w, F_ABB, i);
-            const float rr = F(w, F_RR, i), rg = F(w, F_RG, i), rb = F(w, F_RB, i);
-            if (T == kMaxFloat || !(ap <= 0.999f)) {  // raycast() false, or the absorption test of the loop condition
-                finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces);
-            } else {
-                const Ray ray = load_ray(w, i, kSlotClosest);
-                HitRec rh;
-                materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
-                begin_shade<KERNEL, FUSED>(c, rh, false, bounces, ap + (1.f - ap) * S.cold[rh.index].amb_absorb.w);
+        c.i = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
+        if (!duplicate_entry(w, t, c.i)) resume_pixel<KERNEL, FUSED>(c);
+    }
+    block_push(c.want_closest, c.want_any, (uint32_t)c.i, w.q_closest, w.q_any, w.counts);
+    if (w.count_rays) add_ray_counters(w, c);
+}
+
+// The tail of a frame: once only a sliver of the pixels is still alive (stale-specular light scans, the odd long
+// path), a round costs its fixed price - launch, ~0.1 ms of latency per ray, a host round trip - for almost no work,
+// and that price does not shrink when the frame is split over more GPUs. Here every remaining pixel runs its state
+// machine to the end in one thread, tracing its rays itself through the grid (closest_hit_grid / any_hit_grid: same
+// cells, same exact tests, same results as the wave-level walk).
+template <int KERNEL, bool FUSED>
+__global__ __launch_bounds__(256) void wf_finish(const WfParams w) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t total = w.n_prev_closest + w.n_prev_any;
+    Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u};
+    uint32_t tested = 0;
+    if (t < total) {
+        c.i = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
+        if (!duplicate_entry(w, t, c.i)) {
+            // the queues hold rays that have NOT been traced yet: trace first, then resume, and so on to the end
+            bool do_closest = (t < w.n_prev_closest) || (U(w, F_PHASE, c.i) & PH_FLAG_REFLECTION_PENDING) != 0u;
+            bool do_any = !(t < w.n_prev_closest);
+            for (;;) {
+                if (do_any) {
+                    const Ray ray = load_ray(w, c.i, kSlotShadow);
+                    U(w, F_RES_ANY, c.i) = any_hit_grid<FUSED>(w.grid, w.rp.scene.hot, ray, tested) ? 0u : 1u;
+                }
+                if (do_closest) {
+                    const Ray ray = load_ray(w, c.i, kSlotClosest);
+                    float T = kMaxFloat;
+                    int idx = -1;
+                    closest_hit_grid<FUSED, true>(w.grid, w.rp.scene.hot, ray, T, idx, tested);
+                    F(w, F_RES_T, c.i) = T;
+                    U(w, F_RES_I, c.i) = (uint32_t)idx;
+                }
+                c.want_closest = false;
+                c.want_any = false;
+                resume_pixel<KERNEL, FUSED>(c);
+                if (!c.want_closest && !c.want_any) break;  // the pixel has been written
+                do_closest = c.want_closest;
+                do_any = c.want_any;
             }
         }
     }
-    block_push(c.want_closest, c.want_any, (uint32_t)c.i, w.q_closest, w.q_any, w.counts);
     if (w.count_rays) {
-        const unsigned long long a = wave_sum64(c.traced), b = wave_sum64(c.reference), h = wave_sum64(c.hits);
-        if ((threadIdx.x & 63u) == 0u && (a | b | h)) {
-            atomicAdd(&w.rp.counters->traced, a);
-            atomicAdd(&w.rp.counters->reference, b);
-            atomicAdd(&w.rp.counters->hits, h);
-        }
+        add_ray_counters(w, c);
+        if (tested) atomicAdd(&w.rp.counters->tests, (unsigned long long)tested);
     }
 }
 
@@ -891,6 +934,9 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
     if ((e = hipGetLastError()) != hipSuccess) return e;
     uint32_t rounds = 0;
     bool first = true;
+    // at or below this many live pixels the frame is finished by wf_finish instead of further rounds
+    uint64_t finish_threshold = std::max<uint64_t>(2048, n / 128);
+    if (const char* env = std::getenv("RT_WF_FINISH_THRESHOLD")) finish_threshold = (uint64_t)std::atoll(env);
     for (;;) {
         // how many rays did the last stage queue?  (one small D2H + sync per round; a round is >= N x 35 VALU
         // instructions per ray, so this is noise for the scene sizes this path is used for)
@@ -904,6 +950,11 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
         w.n_prev_closest = nc;
         w.n_prev_any = na;
         const bool use_grid = w.grid.enabled && !w.rp.scene.literal;
+        if (use_grid && !first && (uint64_t)nc + na <= finish_threshold) {
+            hipLaunchKernelGGL((wf_finish<KERNEL, FUSED>), grid_for((uint64_t)nc + na), dim3(256), 0, stream, w);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            break;
+        }
         if (use_grid && (e = hipMemsetAsync(buf.counts + 4, 0, 2 * sizeof(uint32_t), stream)) != hipSuccess) return e;
         // The two launches of a round are independent (different rays, different result words): through the grid they
         // run side by side on two streams, so that each fills the other's tail and a small light-scan queue hides
@@ -923,8 +974,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
             if (use_grid && first && w.tiles.enabled && w.rp.pinhole) {
                 hipLaunchKernelGGL((wf_trace_primary_tiles<FUSED>), grid_for(nc), dim3(256), 0, stream, w, nc);
             } else if (use_grid) {
-                if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest_grid<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
-                else launch_persistent<FUSED, false>(w, w.q_prev_closest, nc, buf.counts + 4, stream);
+                launch_persistent<FUSED, false>(w, w.q_prev_closest, nc, buf.counts + 4, stream);  // (a grid implies direction.w = 0)
             } else {
                 if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
                 else hipLaunchKernelGGL((wf_trace_closest<FUSED, true>), grid_for(nc), dim3(256), 0, stream, w, nc);

@@ -90,3 +90,17 @@ def test_nan_rays_get_the_reference_result(restatement):
     want = restatement[True].render("shade_and_reflect", objs, lights, rays, 3)
     assert ra == want["rays_ref"]
     assert np.abs(a[:, :3].astype(np.float64) - want["out"][:, :3].astype(np.float64)).max() <= 1e-5
+
+
+def test_direction_w_nonzero_falls_back_to_brute_force(restatement):
+    """With direction.w != 0 the reference adds each object's own translation column to the object-space direction:
+    every object sees a different line, so no spatial structure applies. rt_create must not build a grid then, and
+    the result must still be the oracle's."""
+    objs, lights, rays = fuzz_scene(np.random.default_rng(1000 + 3))
+    rays["direction"][:, 3] = 0.5
+    with hip(objs, lights, rays[:1024], 2, path="wavefront", grid=True) as rt:
+        a = rt.Render().copy()
+        t, idx = rt.render_aux()
+    want = restatement[True].render("shade_and_reflect", objs, lights, rays[:1024], 2)
+    assert np.array_equal(idx, want["hit_index"]) and same_floats(t, want["hit_t"])
+    assert np.abs(a[:, :3].astype(np.float64) - want["out"][:, :3].astype(np.float64)).max() <= 1e-5
