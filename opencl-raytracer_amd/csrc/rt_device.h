@@ -218,6 +218,9 @@ __device__ __forceinline__ bool triangle_candidate(float v0x, float v0y, float v
     if (!(v >= 0 && u + v <= 1)) return false;
     const float tt = (e2x * qx + e2y * qy + e2z * qz) * inv;
     if (!(tt >= 0)) return false;
+    // the hit point itself must lie in the guard sphere (for a ray almost in the triangle's plane t is rounding noise)
+    const float hx = (ray.sx + tt * ray.dx) - cx, hy = (ray.sy + tt * ray.dy) - cy, hz = (ray.sz + tt * ray.dz) - cz;
+    if (!(hx * hx + hy * hy + hz * hz <= R * R)) return false;
     t = tt;
     return true;
 }

@@ -7,8 +7,8 @@ parity for triangle scenes is self-parity: the HIP path against the tests' CPU s
 
 Record (the reference's 320-byte ObjectData, `type = 2`):
   mv        columns 0,1,2 = vertices v0,v1,v2 in VIEW space (w = 1); column 3 = (0,0,0,1)
-  mvInverse column 0 = guard sphere (cx, cy, cz, R): centroid of the vertices and the largest vertex distance,
-            rounded to float32 and then R enlarged by 4 ulp - the spec only tests rays whose line passes it
+  mvInverse column 0 = guard sphere (cx, cy, cz, R): centroid of the vertices and 1.01 x the largest vertex distance
+            (float32, rounded up) - the spec only accepts hits whose line passes it AND whose point lies in it
   material  as for the other primitives
 
 Winding: counter-clockwise seen from outside, so normalize((v1-v0) x (v2-v0)) is the outward normal.
@@ -43,9 +43,7 @@ def triangle_records(v0, v1, v2, template: np.ndarray) -> np.ndarray:
     c = ((d0 + d1 + d2) / 3.0).astype(F)
     cd = c.astype(np.float64)
     r = np.sqrt(np.maximum.reduce([((d0 - cd) ** 2).sum(1), ((d1 - cd) ** 2).sum(1), ((d2 - cd) ** 2).sum(1)]))
-    rf = r.astype(F)
-    for _ in range(4):
-        rf = np.nextafter(rf, F(np.inf))
+    rf = np.nextafter((r * 1.01).astype(F), F(np.inf))   # 1 % of slack: a hit on the farthest vertex must pass the point test
     inv = np.zeros((n, 4, 4), dtype=F)
     inv[:, 0, :3] = c
     inv[:, 0, 3] = rf

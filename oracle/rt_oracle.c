@@ -137,7 +137,10 @@ static inline void materialise(Hit* hit, const float* obj, const float* p, const
  *           product form keeps its rounding error ~1e-7 R |oc|, far below the discriminant form's ~1e-6 |oc|^2)
  *   Moeller-Trumbore, two-sided: e1 = v1 - v0, e2 = v2 - v0, p = d x e2, det = e1.p (0 or NaN -> miss),
  *   inv = 1/det, tv = start - v0, u = (tv.p) inv in [0,1], q = tv x e1, v = (d.q) inv >= 0, u + v <= 1,
- *   t = (e2.q) inv >= 0. Ties in t: the earlier object wins (like the box). Normal = normalize(e1 x e2). */
+ *   t = (e2.q) inv >= 0; and the point h = start + t d (one product, one sum per component) must itself lie in the
+ *   guard sphere, (h - c).(h - c) <= R R: for a ray almost in the triangle's plane t is a ratio of rounding noise,
+ *   and this keeps such a "hit" on the chord of the guard sphere instead of anywhere along the ray.
+ *   Ties in t: the earlier object wins (like the box). Normal = normalize(e1 x e2). */
 static inline void cross3(float* o, const float* a, const float* b) {
     o[0] = a[1] * b[2] - a[2] * b[1];
     o[1] = a[2] * b[0] - a[0] * b[2];
@@ -167,6 +170,9 @@ static int triangle_hit(const float* obj, const float* ray, float* t_out, float*
     if (!(v >= 0 && u + v <= 1)) return 0;
     const float t = dot3p(e2, q) * inv;
     if (!(t >= 0)) return 0;
+    float hc[3];
+    for (int i = 0; i < 3; ++i) hc[i] = (s[i] + t * d[i]) - gs[i];
+    if (!(dot3p(hc, hc) <= gs[3] * gs[3])) return 0;
     *t_out = t;
     cross3(normal_out, e1, e2);
     return 1;
