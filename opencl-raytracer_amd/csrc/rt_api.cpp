@@ -759,6 +759,40 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
                 if (total) RT_HIP(c, hipMemcpy(c->d_grid_entry_sphere, es.data(), sizeof(float4) * total, hipMemcpyHostToDevice));
                 std::vector<uint2> ranges(n_cells);
                 for (size_t k = 0; k < n_cells; ++k) ranges[k] = make_uint2(start[k], start[k + 1] - start[k]);
+                // Empty cells carry, in the unused offset word, how many FURTHER steps of a walk are sure to land in
+                // empty cells too: the Chebyshev distance to the nearest occupied cell minus one (a walk moves by one
+                // face per step), from a two-pass chamfer over the 26-neighbourhood, capped at 255. The grid walk
+                // takes those steps without fetching their records (meshes leave most of a grid empty).
+                if (n_cells <= (64ull << 20)) {
+                    std::vector<uint8_t> dist(n_cells);
+                    for (size_t k = 0; k < n_cells; ++k) dist[k] = ranges[k].y ? 0 : 255;
+                    const int nx = dim[0], ny = dim[1], nz = dim[2];
+                    auto at = [&](int x, int y, int z) -> uint8_t& { return dist[((size_t)z * ny + y) * nx + x]; };
+                    for (int pass = 0; pass < 2; ++pass) {
+                        const int z0 = pass ? nz - 1 : 0, z1 = pass ? -1 : nz, dz = pass ? -1 : 1;
+                        for (int z = z0; z != z1; z += dz)
+                            for (int y = pass ? ny - 1 : 0; y != (pass ? -1 : ny); y += dz)
+                                for (int x = pass ? nx - 1 : 0; x != (pass ? -1 : nx); x += dz) {
+                                    uint8_t& d = at(x, y, z);
+                                    if (d == 0) continue;
+                                    int best = d;
+                                    // the 13 neighbours already visited in this scan direction
+                                    for (int oz = -1; oz <= 0; ++oz)
+                                        for (int oy = -1; oy <= (oz ? 1 : 0); ++oy)
+                                            for (int ox = -1; ox <= ((oz || oy) ? 1 : -1); ++ox) {
+                                                const int X = x + ox * dz, Y = y + oy * dz, Z = z + oz * dz;
+                                                if ((unsigned)X >= (unsigned)nx || (unsigned)Y >= (unsigned)ny || (unsigned)Z >= (unsigned)nz) continue;
+                                                best = std::min(best, (int)at(X, Y, Z) + 1);
+                                            }
+                                    d = (uint8_t)best;
+                                }
+                    }
+                    for (size_t k = 0; k < n_cells; ++k)
+                        if (ranges[k].y == 0) ranges[k].x = dist[k] > 1 ? (uint32_t)dist[k] - 1u : 0u;
+                } else {
+                    for (size_t k = 0; k < n_cells; ++k)
+                        if (ranges[k].y == 0) ranges[k].x = 0u;
+                }
                 RT_HIP(c, hipMalloc((void**)&c->d_grid_cell_range, sizeof(uint2) * n_cells));
                 RT_HIP(c, hipMemcpy(c->d_grid_cell_range, ranges.data(), sizeof(uint2) * n_cells, hipMemcpyHostToDevice));
             }

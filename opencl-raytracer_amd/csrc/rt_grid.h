@@ -48,7 +48,8 @@ struct GridDesc {
     float inv_cell;             // 1 / cell edge
     float cell;                 // cell edge
     int nx, ny, nz;
-    const uint2* __restrict__ cell_range;     // nx*ny*nz x {first entry, number of entries}
+    const uint2* __restrict__ cell_range;     // nx*ny*nz x {first entry, number of entries}; an EMPTY cell's first word is
+                                              // the number of further walk steps that are sure to stay in empty cells
     const uint32_t* __restrict__ entries;     // object indices, ascending inside a cell
     const float4* __restrict__ entry_sphere;  // parallel to entries: the object's inflated bounding sphere (centre, R_grid)
     const uint32_t* __restrict__ always;      // objects every ray must test
@@ -303,7 +304,7 @@ __device__ __forceinline__ void closest_hit_grid(const GridDesc& g, const HotObj
     for (;;) {
         const uint32_t c = ((uint32_t)w.iz * (uint32_t)g.ny + (uint32_t)w.iy) * (uint32_t)g.nx + (uint32_t)w.ix;
         const uint2 range = g.cell_range[c];
-        const uint32_t e0 = range.x, e1 = range.x + range.y;
+        const uint32_t e0 = range.x, e1 = range.y ? range.x + range.y : range.x;
         tested += e1 - e0;
         for (uint32_t e = e0; e < e1; ++e) {
             const int k = (int)g.entries[e];
