@@ -541,3 +541,23 @@ def test_randomised_configurations_vs_oracle(seed, restatement):
         assert same_floats(out, want["out"])
     else:
         assert compare_frames(out, want["out"]) <= RGB_ATOL
+
+
+def test_config4_full_frame_grid_equals_brute_force():
+    """BASELINE configs[3] at full size (100 000 spheres, 32 lights, 4096 x 4096, depth 3): the default (grid) path
+    and the brute-force path - which tests every object for every one of the 109 M rays - produce the same 16.7 M
+    pixels bit for bit, trace the same number of rays and agree on every primary hit."""
+    from opencl_raytracer_amd import synthetic
+    objs, lights = synthetic.spheres_and_lights(100_000, 32)
+    W = H = 4096
+    z = float(camera.camera_z(H))
+    res = {}
+    for grid in (True, False):
+        with hip(objs, lights, None, 3, camera=(W, H, z), grid=grid) as rt:
+            out = rt.Render()
+            t, idx = rt.render_aux()
+            st = rt.count_rays()
+            res[grid] = (out.view(np.uint32).copy(), t.view(np.uint32).copy(), idx.copy(), st.rays_reference, st.rays_traced, st.hit_pixels)
+    a, b = res[True], res[False]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert a[3:] == b[3:] and a[3] == 1690436982 and a[5] == 16694242

@@ -143,3 +143,42 @@ def test_triangle_soup_fuzz_vs_oracle(restatement, seed):
     rays["start"][:, 3] = 1.0
     want = _check(tri, lights, rays, 2, restatement[True], kernels=("hittest", "shade_and_reflect"))
     assert int((want["hit_index"] >= 0).sum()) > m // 10
+
+
+def test_config5_million_triangles_8192_properties(restatement):
+    """BASELINE configs[4] at full size: roundedCube.txt tessellated to ~1 M triangles, 8192 x 8192, depth 5. The CPU
+    statement tests every triangle for every ray, so it checks a 16 x 16 window of the frame (nearest t, index and
+    colour); the whole frame is checked through properties: deterministic, every primary hit is a triangle whose
+    guard sphere the pixel's ray passes, and the hit mask stays close to the analytic scene's."""
+    objs, lights = scene_loader.load_scene(str(SCENES / "roundedCube.txt"))
+    lat, lon, k = T.subdivision_for(objs, 1_000_000)
+    tri = T.tessellate(objs, lat, lon, k)
+    assert 900_000 < len(tri) < 1_100_000
+    W = H = 8192
+    z = float(camera.camera_z(H))
+    with hip(tri, lights, None, 5, camera=(W, H, z)) as rt:
+        a = rt.Render().copy()
+        t, idx = rt.render_aux()
+        b = rt.Render()
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        st = rt.count_rays()
+    x0, y0, e = W // 2 - 8, H // 2 - 8, 16
+    rays = camera.crop_rays(W, H, x0, y0, e, e)
+    want = restatement[True].render("shade_and_reflect", tri, lights, rays, 5)
+    rows = (np.arange(y0, y0 + e)[:, None] * W + np.arange(x0, x0 + e)[None, :]).reshape(-1)
+    assert np.array_equal(idx[rows], want["hit_index"]) and np.array_equal(t[rows].view(np.uint32), want["hit_t"].view(np.uint32))
+    assert np.abs(a[rows, :3].astype(np.float64) - want["out"][:, :3].astype(np.float64)).max() <= RGB_ATOL
+    hit = idx >= 0
+    assert int(hit.sum()) == st.hit_pixels and st.hit_pixels > 10_000_000
+    # every hit lies in the guard sphere of the triangle it reports (sampled)
+    sel = np.nonzero(hit)[0][:: max(1, int(hit.sum()) // 200_000)]
+    gs = tri["mvInverse"][idx[sel]][:, :4].astype(np.float64)
+    col = (sel % W).astype(np.float64) - W / 2.0
+    row = (H - (sel // W)).astype(np.float64) - H / 2.0
+    d = np.stack([col, row, np.full(len(sel), z, dtype=np.float64)], axis=1)
+    p = d * t[sel].astype(np.float64)[:, None]
+    assert np.all(np.linalg.norm(p - gs[:, :3], axis=1) <= gs[:, 3] * (1 + 1e-4))
+    with hip(objs, lights, None, 5, camera=(W, H, z)) as rt:
+        rt.Render()
+        _, idx_analytic = rt.render_aux()
+    assert ((idx_analytic >= 0) != hit).mean() < 1e-3
