@@ -338,12 +338,28 @@ def main():
                                           "rt::wf_trace_closest + rt::wf_trace_any_slice") + " (+ wf_resume, wf_begin)",
                                "kernel_ms": kernel_ms, "object_tests": tests,
                                "tests_per_s": tests / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0, "hbm": hbm}
+            isf = ROOT / "profiles" / f"issue_{args.workload}.json"
+            if culled and world == 1 and isf.exists():
+                # what the grid path IS bound by: issue of vector instructions (PMC count of one frame, tools/pmc_issue.sh,
+                # divided by the live kernel time of this run; ~4 cycles per wave-instruction for this instruction mix)
+                try:
+                    isd = json.loads(isf.read_text())
+                    rate = isd["valu_wave_instructions"] / (kernel_ms * 1e-3)
+                    out["roofline"]["valu_issue"] = {
+                        "bound": "valu_issue", "achieved": rate / 1e9, "peak": isd["peak_valu_wave_instructions_per_s"] / 1e9,
+                        "unit": "G wave-instr/s", "frac": rate / isd["peak_valu_wave_instructions_per_s"],
+                        "lanes_per_instruction": isd["lanes_per_valu_instruction"],
+                        "waves_waiting_frac": isd["wait_quad_cycles"] / isd["wave_quad_cycles"],
+                        "source": "profiles/issue_cfg4.json (rocprofv3 --pmc SQ_INSTS_VALU ..., one frame) / live kernel time"}
+                except Exception:
+                    pass
             if culled:
                 out["roofline"]["note"] = ("default path = conservative grid culling: %.1f exact ray-object tests per traced ray instead of %d "
                                            "(each preceded by ~5 16-byte bounding-sphere pre-tests and ~5 cell steps); the walk is bound by the "
                                            "issue of its bookkeeping instructions and by L2 latency, not by the 35-instruction tests this "
-                                           "roofline counts, so its fraction is small by design - the brute-force traversal kernels it "
-                                           "replaces, which ARE bound by those tests, are reported in brute_force") % (
+                                           "roofline counts, so its fraction is small by design (valu_issue = the issue-slot view of the same "
+                                           "frame) - the brute-force traversal kernels it replaces, which ARE bound by those tests, are "
+                                           "reported in brute_force") % (
                                                tests / max(rays_act, 1), len(objs))
                 if world == 1 and not args.no_extra:
                     out["roofline"]["brute_force"] = measure_brute_force_window(local_rank, 4096)
