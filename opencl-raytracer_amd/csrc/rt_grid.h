@@ -249,8 +249,9 @@ __device__ __forceinline__ bool walk_next(const GridDesc& g, Walk& w) {
 struct LeanWalk {
     int c;                 // current cell (linear index)
     int rx, ry, rz;        // steps left along each axis before the walk leaves the grid
-    int sx, sy, sz;        // index stride of one step along each axis (+-1, +-nx, +-nx*ny)
-    float tx, ty, tz, dtx, dty, dtz, t_enter;
+    float tx, ty, tz;      // ray parameter at the next x / y / z cell wall
+    float dtx, dty, dtz;   // parameter advance per cell, carrying the SIGN of the step along that axis
+    float t_enter;
 };
 
 __device__ __forceinline__ LeanWalk lean_walk(const GridDesc& g, const Walk& w) {
@@ -259,24 +260,29 @@ __device__ __forceinline__ LeanWalk lean_walk(const GridDesc& g, const Walk& w) 
     k.rx = w.stepx > 0 ? g.nx - 1 - w.ix : w.ix;
     k.ry = w.stepy > 0 ? g.ny - 1 - w.iy : w.iy;
     k.rz = w.stepz > 0 ? g.nz - 1 - w.iz : w.iz;
-    k.sx = w.stepx; k.sy = w.stepy * g.nx; k.sz = w.stepz * g.nx * g.ny;
-    k.tx = w.tx; k.ty = w.ty; k.tz = w.tz; k.dtx = w.dtx; k.dty = w.dty; k.dtz = w.dtz;
+    k.tx = w.tx; k.ty = w.ty; k.tz = w.tz;
+    k.dtx = w.stepx > 0 ? w.dtx : -w.dtx;
+    k.dty = w.stepy > 0 ? w.dty : -w.dty;
+    k.dtz = w.stepz > 0 ? w.dtz : -w.dtz;
     k.t_enter = w.t_enter;
     return k;
 }
 
-__device__ __forceinline__ bool lean_next(LeanWalk& k) {
+__device__ __forceinline__ bool lean_next(const GridDesc& g, LeanWalk& k) {
     // written with plain selects of 0 / value so that the fields stay in registers (an indexed pick of
-    // tx/ty/tz or sx/sy/sz makes the compiler move the struct to LDS)
+    // tx/ty/tz makes the compiler move the struct to LDS)
     const float tmin = __builtin_fminf(__builtin_fminf(k.tx, k.ty), k.tz);
     const bool ax = (k.tx <= k.ty) && (k.tx <= k.tz);
     const bool ay = !ax && (k.ty <= k.tz);
     const bool az = !ax && !ay;
     k.t_enter = tmin;
-    k.tx += ax ? k.dtx : 0.f;
-    k.ty += ay ? k.dty : 0.f;
-    k.tz += az ? k.dtz : 0.f;
-    k.c += (ax ? k.sx : 0) + (ay ? k.sy : 0) + (az ? k.sz : 0);
+    k.tx += ax ? __builtin_fabsf(k.dtx) : 0.f;
+    k.ty += ay ? __builtin_fabsf(k.dty) : 0.f;
+    k.tz += az ? __builtin_fabsf(k.dtz) : 0.f;
+    const int sx = k.dtx < 0.f ? -1 : 1;
+    const int sy = k.dty < 0.f ? -g.nx : g.nx;
+    const int sz = k.dtz < 0.f ? -(g.nx * g.ny) : g.nx * g.ny;
+    k.c += (ax ? sx : 0) + (ay ? sy : 0) + (az ? sz : 0);
     k.rx -= ax ? 1 : 0;
     k.ry -= ay ? 1 : 0;
     k.rz -= az ? 1 : 0;

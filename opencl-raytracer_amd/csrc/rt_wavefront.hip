@@ -339,7 +339,6 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
     }
     const GridDesc& g = w.grid;
     const HotObject* __restrict__ hot = w.rp.scene.hot;
-    const unsigned long long below = (1ull << lane) - 1ull;
 
     unsigned long long s_rays = 0, s_trips = 0, s_live = 0, s_fetch = 0, s_pre = 0, s_flush = 0, s_refill = 0;  // STATS only
     int st = 0;            // 0 idle (needs a ray), 1 at a cell whose list has not been fetched, 2 walking a list, 3 walk over
@@ -357,7 +356,8 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         // ---- hand out rays to idle lanes ----
         const unsigned long long idle = __ballot(st == 0);
         if (next < seg_end && ((uint32_t)__popcll(idle) >= (uint32_t)RT_REFILL_MIN || idle == ~0ull)) {
-            const uint32_t mine = next + (uint32_t)__popcll(idle & below);
+            // rank of this lane among the idle ones (mbcnt: set bits of the mask below this lane)
+            const uint32_t mine = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             if (STATS && lane == 0u) ++s_refill;
             if (st == 0 && mine < seg_end) {
                 if (STATS) ++s_rays;
@@ -421,10 +421,10 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         // ---- step to the next cell, or end the walk ----
         if (advance) {
             const float limit = ANY ? 1.0f + slack : T + slack;
-            bool stop = !lean_next(wk) || wk.t_enter > limit;
+            bool stop = !lean_next(g, wk) || wk.t_enter > limit;
             while (skip != 0u && !stop) {  // empty space: step on without fetching (same cells, same order, same checks)
                 --skip;
-                stop = !lean_next(wk) || wk.t_enter > limit;
+                stop = !lean_next(g, wk) || wk.t_enter > limit;
             }
             skip = 0u;
             st = stop ? 3 : 1;
@@ -469,7 +469,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
 }
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 6      // <= 80 VGPRs: fits without spills when the triangle branch is compiled out
+#define RT_WAVES_PER_EU 7      // <= 72 VGPRs (closest-hit variant: no spills, shadow variant: 24 B) - 24.5 vs 24.85 ms at 6
 #endif
 #ifndef RT_WAVES_PER_EU_TRI
 #define RT_WAVES_PER_EU_TRI 6  // the variants that know triangles would like ~90 VGPRs; 5 waves without spills measured slower (97.6 vs 93 ms, cfg5)
