@@ -97,17 +97,19 @@ __device__ __forceinline__ Ray load_ray(const WfParams& w, uint64_t i, uint32_t 
     r.dx = d.x; r.dy = d.y; r.dz = d.z; r.dw = d.w;
     return r;
 }
-__device__ __forceinline__ void store_hit(const WfParams& w, uint64_t i, const HitRec& h) {
+// (the reflection vector is only kept when the reflection ray has not been sent with the hit - begin_shade_lit)
+__device__ __forceinline__ void store_hit(const WfParams& w, uint64_t i, const HitRec& h, bool with_reflection) {
     F(w, F_PX, i) = h.px; F(w, F_PY, i) = h.py; F(w, F_PZ, i) = h.pz; F(w, F_PW, i) = h.pw;
     F(w, F_NX, i) = h.nx; F(w, F_NY, i) = h.ny; F(w, F_NZ, i) = h.nz;
-    F(w, F_RX, i) = h.rx; F(w, F_RY, i) = h.ry; F(w, F_RZ, i) = h.rz;
+    if (with_reflection) { F(w, F_RX, i) = h.rx; F(w, F_RY, i) = h.ry; F(w, F_RZ, i) = h.rz; }
     U(w, F_HIDX, i) = (uint32_t)h.index;
 }
-__device__ __forceinline__ HitRec load_hit(const WfParams& w, uint64_t i) {
+__device__ __forceinline__ HitRec load_hit(const WfParams& w, uint64_t i, bool with_reflection) {
     HitRec h;
     h.px = F(w, F_PX, i); h.py = F(w, F_PY, i); h.pz = F(w, F_PZ, i); h.pw = F(w, F_PW, i);
     h.nx = F(w, F_NX, i); h.ny = F(w, F_NY, i); h.nz = F(w, F_NZ, i);
-    h.rx = F(w, F_RX, i); h.ry = F(w, F_RY, i); h.rz = F(w, F_RZ, i);
+    h.rx = h.ry = h.rz = 0.f;
+    if (with_reflection) { h.rx = F(w, F_RX, i); h.ry = F(w, F_RY, i); h.rz = F(w, F_RZ, i); }
     h.index = (int)U(w, F_HIDX, i);
     return h;
 }
@@ -121,7 +123,10 @@ __device__ __forceinline__ void push(uint32_t* queue, uint32_t* counter, uint64_
 // Queue appends of a whole workgroup with ONE atomic per queue: a single global counter takes ~88 returning
 // atomics per microsecond on this chip, so one per wave (262 144 waves per round at 4096^2) would cost 3 ms a
 // round. Order inside the workgroup is preserved (neighbouring pixels stay neighbours in the next trace).
-constexpr int kResumeThreads = 1024;
+#ifndef RT_RESUME_THREADS
+#define RT_RESUME_THREADS 1024
+#endif
+constexpr int kResumeThreads = RT_RESUME_THREADS;
 __device__ __forceinline__ void block_push(bool want_closest, bool want_any, uint32_t id, uint32_t* __restrict__ q_closest,
                                            uint32_t* __restrict__ q_any, uint32_t* __restrict__ counts) {
     __shared__ uint32_t s_cnt[2][kResumeThreads / 64];
@@ -587,9 +592,11 @@ template <int KERNEL, bool FUSED> __device__ void shade_done(Ctx& c, const HitRe
 template <int KERNEL, bool FUSED>
 __device__ __forceinline__ void begin_shade_lit(Ctx& c, const HitRec& h, bool primary, uint32_t spec_bounces, float spec_ap) {
     const Scene& S = c.w.rp.scene;
-    store_hit(c.w, c.i, h);
     c.reference += S.n_lights;
     uint32_t flag = 0u;
+    // shade_and_reflect outside literal mode never needs the stored reflection vector: either the ray leaves now, or
+    // loop_step() will decide - under this same condition - that there is none
+    store_hit(c.w, c.i, h, !(KERNEL == 2 && !S.literal));
     if (KERNEL == 2 && !S.literal && spec_bounces > 0u && spec_ap <= 0.999f) {
         Ray ray;
         reflection_ray<FUSED>(h, ray);
@@ -607,7 +614,7 @@ __device__ __forceinline__ void begin_shade_lit(Ctx& c, const HitRec& h, bool pr
 // ... or, without lights, go straight on (shade() returns black)
 template <int KERNEL, bool FUSED>
 __device__ __forceinline__ void begin_shade(Ctx& c, const HitRec& h, bool primary, uint32_t spec_bounces, float spec_ap) {
-    if (c.w.rp.scene.n_lights == 0) { store_hit(c.w, c.i, h); shade_done<KERNEL, FUSED>(c, h, primary, 0.f, 0.f, 0.f); return; }
+    if (c.w.rp.scene.n_lights == 0) { store_hit(c.w, c.i, h, true); shade_done<KERNEL, FUSED>(c, h, primary, 0.f, 0.f, 0.f); return; }
     begin_shade_lit<KERNEL, FUSED>(c, h, primary, spec_bounces, spec_ap);
 }
 
@@ -617,7 +624,7 @@ template <int KERNEL, bool FUSED>
 __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
     const Scene& S = c.w.rp.scene;
     const uint64_t i = c.i;
-    const HitRec h = load_hit(c.w, i);
+    const HitRec h = load_hit(c.w, i, !(KERNEL == 2 && !S.literal));
     const uint32_t li = U(c.w, F_LI, i);
     const bool lit = U(c.w, F_RES_ANY, i) != 0u;
     const ColdObject* co = S.cold + h.index;
