@@ -59,6 +59,7 @@ struct WfParams {
     ScreenTiles tiles;            // screen-tile object lists for pinhole primary rays
     uint32_t n_prev_closest, n_prev_any;
     int kernel;
+    uint32_t first_round;  // the closest-hit rays of this round are the primary rays (never stored: closest_ray())
     uint32_t count_rays;  // instrumentation on
 };
 
@@ -164,23 +165,15 @@ __global__ __launch_bounds__(kResumeThreads) void wf_begin(const WfParams w) {
     block_push(want, false, (uint32_t)i, w.q_closest, w.q_any, w.counts);
 }
 
-__device__ __forceinline__ bool begin_pixel(const WfParams& w, uint64_t i) {
-    const RenderParams& p = w.rp;
+// global ray index of work-item i (shards: interleaved tiles), and the primary ray itself - regenerated (pinhole) or
+// re-read from the upload buffer wherever it is needed; it is never copied into the pixel state
+__device__ __forceinline__ uint64_t global_ray_of(const RenderParams& p, uint64_t i) {
     const uint64_t px = pixel_of(p, i);
-    uint64_t g = px;
-    if (p.world > 1u) {
-        const uint64_t tile = px / p.tile_rays;
-        const uint64_t off = px - tile * p.tile_rays;
-        g = (tile * p.world + p.rank) * p.tile_rays + off;
-    }
-    if (g >= p.n_rays) {  // padding work-item of a ragged last tile
-        if (w.kernel == 0) reinterpret_cast<float*>(p.out)[px] = kMaxFloat;
-        else reinterpret_cast<float4*>(p.out)[px] = make_float4(0.f, 0.f, 0.f, 1.0f);
-        if (p.aux_t) p.aux_t[px] = kMaxFloat;
-        if (p.aux_index) p.aux_index[px] = -1;
-        U(w, F_PHASE, i) = PH_DONE;
-        return false;
-    }
+    if (p.world <= 1u) return px;
+    const uint64_t tile = px / p.tile_rays;
+    return (tile * p.world + p.rank) * p.tile_rays + (px - tile * p.tile_rays);
+}
+__device__ __forceinline__ Ray primary_ray(const RenderParams& p, uint64_t g) {
     Ray ray;
     if (p.pinhole) {
         const uint32_t gi = (uint32_t)g;
@@ -197,7 +190,24 @@ __device__ __forceinline__ bool begin_pixel(const WfParams& w, uint64_t i) {
         ray.sx = s.x; ray.sy = s.y; ray.sz = s.z; ray.sw = s.w;
         ray.dx = d.x; ray.dy = d.y; ray.dz = d.z; ray.dw = d.w;
     }
-    store_ray(w, i, ray, kSlotClosest);
+    return ray;
+}
+// the closest-hit ray pixel i has (or had) in flight
+__device__ __forceinline__ Ray closest_ray(const WfParams& w, uint64_t i, bool primary) {
+    return primary ? primary_ray(w.rp, global_ray_of(w.rp, i)) : load_ray(w, i, kSlotClosest);
+}
+
+__device__ __forceinline__ bool begin_pixel(const WfParams& w, uint64_t i) {
+    const RenderParams& p = w.rp;
+    if (global_ray_of(p, i) >= p.n_rays) {  // padding work-item of a ragged last tile
+        const uint64_t px = pixel_of(p, i);
+        if (w.kernel == 0) reinterpret_cast<float*>(p.out)[px] = kMaxFloat;
+        else reinterpret_cast<float4*>(p.out)[px] = make_float4(0.f, 0.f, 0.f, 1.0f);
+        if (p.aux_t) p.aux_t[px] = kMaxFloat;
+        if (p.aux_index) p.aux_index[px] = -1;
+        U(w, F_PHASE, i) = PH_DONE;
+        return false;
+    }
     U(w, F_PHASE, i) = PH_PRIMARY;
     return true;
 }
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256) void wf_trace_closest(const WfParams w, uint32
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_queue) return;
     const uint64_t i = w.q_prev_closest[t];
-    const Ray ray = load_ray(w, i, kSlotClosest);
+    const Ray ray = closest_ray(w, i, w.first_round != 0u);
     float T = kMaxFloat;
     int idx = -1;
     closest_hit<FUSED, DW0>(w.rp.scene.pairs, w.rp.scene.n_pairs, ray, T, idx);
@@ -244,13 +254,8 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams w, 
     if (t >= n_queue) return;
     const RenderParams& p = w.rp;
     const uint64_t i = w.q_prev_closest[t];
-    const Ray ray = load_ray(w, i, kSlotClosest);
-    const uint64_t px = pixel_of(p, i);
-    uint64_t g = px;
-    if (p.world > 1u) {
-        const uint64_t tile = px / p.tile_rays;
-        g = (tile * p.world + p.rank) * p.tile_rays + (px - tile * p.tile_rays);
-    }
+    const uint64_t g = global_ray_of(p, i);
+    const Ray ray = primary_ray(p, g);
     const uint32_t row = (uint32_t)g / p.width, col = (uint32_t)g - row * p.width;
     const uint32_t tile = (row >> 3) * w.tiles.tiles_x + (col >> 6);
     const uint32_t first = __builtin_amdgcn_readfirstlane(tile);
@@ -367,7 +372,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             if (st == 0 && mine < seg_end) {
                 if (STATS) ++s_rays;
                 pix = queue[mine];
-                ray = load_ray(w, pix, ANY ? kSlotShadow : kSlotClosest);
+                ray = ANY ? load_ray(w, pix, kSlotShadow) : closest_ray(w, pix, w.first_round != 0u);
                 ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
                 T = kMaxFloat; idx = -1; cur_sphere = false; pend = false;
                 bool done = false;
@@ -540,11 +545,11 @@ __global__ __launch_bounds__(256) void wf_trace_any_slice(const WfParams w, cons
 // tests is a comparison that NaN fails. In practice these are reflections off a box hit whose object-space point
 // has no coordinate beyond 0.4998 (tiny far boxes: 0/0 normal). The brute-force kernels reproduce that by
 // construction; for the grid path it is patched in here, where the result is consumed.
-__device__ __forceinline__ void closest_result(const WfParams& w, uint64_t i, float& T, int& idx) {
+__device__ __forceinline__ void closest_result(const WfParams& w, uint64_t i, bool primary, float& T, int& idx) {
     T = F(w, F_RES_T, i);
     idx = (int)U(w, F_RES_I, i);
     if (T == kMaxFloat && w.grid.enabled && !w.rp.scene.literal && w.grid.nan_winner >= 0) {
-        const Ray ray = load_ray(w, i, kSlotClosest);
+        const Ray ray = closest_ray(w, i, primary);
         if (ray_has_nan(ray)) { T = __builtin_nanf(""); idx = w.grid.nan_winner; }
     }
 }
@@ -738,7 +743,7 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
         const uint64_t i = c.i;
         float T;
         int idx;
-        closest_result(c.w, i, T, idx);
+        closest_result(c.w, i, false, T, idx);
         if (T == kMaxFloat) { finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces); return; }
         const Ray ray = load_ray(c.w, i, kSlotClosest);
         HitRec rh;
@@ -788,7 +793,7 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
     if (phase == PH_PRIMARY) {
         float T;
         int idx;
-        closest_result(w, i, T, idx);
+        closest_result(w, i, true, T, idx);
         const bool hit = (KERNEL == 2) ? !(T == kMaxFloat) : (T < kMaxFloat);
         c.traced += 1; c.reference += 1; c.hits += hit ? 1 : 0;
         if (w.rp.aux_t) w.rp.aux_t[pixel_of(w.rp, i)] = T;
@@ -799,7 +804,7 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
         } else if (!hit) {
             write_pixel<KERNEL>(c, 0.f, 0.f, 0.f);
         } else {
-            const Ray ray = load_ray(w, i, kSlotClosest);
+            const Ray ray = closest_ray(w, i, true);
             HitRec h;
             materialise<FUSED>(S.hot, S.cold, idx, T, ray, h);
             begin_shade<KERNEL, FUSED>(c, h, true, w.rp.max_bounces, S.cold[h.index].amb_absorb.w);
@@ -811,7 +816,7 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
     } else if (phase == PH_REFLECT) {
         float T;
         int idx;
-        closest_result(w, i, T, idx);
+        closest_result(w, i, false, T, idx);
         const float ap = F(w, F_AP, i);
         const uint32_t bounces = U(w, F_BOUNCES, i);
         const float abr = F(w, F_ABR, i), abg = F(w, F_ABG, i), abb = F(w, F_ABB, i);
@@ -965,6 +970,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
         w.q_prev_any = q[cur][1];
         w.n_prev_closest = nc;
         w.n_prev_any = na;
+        w.first_round = first ? 1u : 0u;
         const bool use_grid = w.grid.enabled && !w.rp.scene.literal;
         if (use_grid && !first && (uint64_t)nc + na <= finish_threshold) {
             hipLaunchKernelGGL((wf_finish<KERNEL, FUSED>), grid_for((uint64_t)nc + na), dim3(256), 0, stream, w);
