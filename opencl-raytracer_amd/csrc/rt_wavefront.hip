@@ -847,8 +847,11 @@ __device__ __forceinline__ void add_ray_counters(const WfParams& w, const Ctx& c
     }
 }
 
+#ifndef RT_RESUME_WAVES_PER_EU
+#define RT_RESUME_WAVES_PER_EU 4
+#endif
 template <int KERNEL, bool FUSED>
-__global__ __launch_bounds__(kResumeThreads) void wf_resume(const WfParams w) {
+__global__ __launch_bounds__(kResumeThreads) __attribute__((amdgpu_waves_per_eu(RT_RESUME_WAVES_PER_EU))) void wf_resume(const WfParams w) {
     const uint32_t t = blockIdx.x * kResumeThreads + threadIdx.x;
     const uint32_t total = w.n_prev_closest + w.n_prev_any;
     Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u};
