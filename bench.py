@@ -53,6 +53,33 @@ WORKLOADS = {
 }
 
 
+def library_sha16():
+    """sha-256 (first 16 hex digits) of the C-ABI library this process loads - the stamp tools/pmc_frame.sh puts on the
+    counter files it writes."""
+    import hashlib
+    from opencl_raytracer_amd import hip_raytracer
+    path = os.environ.get("RT_LIB_OVERRIDE", str(hip_raytracer.LIB_PATH))
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+def frame_profile(workload):
+    """profiles/frame_<workload>.json (rocprofv3 PMC + kernel trace of one frame, tools/pmc_frame.sh) - but only when it
+    was measured on THIS build of the library; otherwise (None, reason): a counter file of another build says nothing
+    about the kernels that are running now."""
+    path = ROOT / "profiles" / f"frame_{workload}.json"
+    if not path.exists():
+        return None, f"profiles/frame_{workload}.json not collected (tools/pmc_frame.sh {workload})"
+    try:
+        d = json.loads(path.read_text())
+    except Exception as ex:  # noqa: BLE001
+        return None, f"profiles/frame_{workload}.json unreadable: {ex}"
+    have = library_sha16()
+    if d.get("lib_sha16") != have:
+        return None, (f"profiles/frame_{workload}.json was measured on library {d.get('lib_sha16')}, this run uses {have}: "
+                      "counters not quoted (re-run tools/pmc_frame.sh)")
+    return d, None
+
+
 def load_workload(name):
     desc, scene, W, H, kernel, depth = WORKLOADS[name]
     if scene is not None:
@@ -168,18 +195,19 @@ def measure_cfg3(device_index):
     ms_sum, n = rt.timing_summary()
     kernel_ms = ms_sum / max(n, 1)
     alg = 16 * W * H + 320 * len(objs) + 64 * len(lights)
-    traffic = None
-    tf = ROOT / "profiles" / "traffic_cfg3.json"
-    if tf.exists():
-        try:
-            traffic = json.loads(tf.read_text())["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+    prof, why = frame_profile("cfg3")
+    traffic = prof["hbm_bytes_per_launch"] if prof else None
+    roof = {"bound": "hbm", "achieved": alg / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rt::render_pixels<2,true,false>",
+            "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg}
+    if prof:
+        roof["traffic_over_algorithmic"] = traffic / alg
+        roof["traffic_source"] = f"profiles/frame_cfg3.json (rocprofv3 PMC, library {prof['lib_sha16']})"
+    else:
+        roof["traffic_unavailable"] = why
     res = {"workload": desc, "value": st.rays_reference / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3, "steps": steps,
            "rays_reference": int(st.rays_reference), "rays_traced": int(st.rays_traced), "hit_pixels": int(st.hit_pixels),
-           "roofline": {"bound": "hbm", "achieved": alg / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rt::render_pixels<2,true,false>",
-                        "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg}}
+           "mrays_traced_per_s": st.rays_traced / dt / 1e6, "roofline": roof}
     rt.close()
     return res
 
@@ -302,13 +330,8 @@ def main():
         local = rt.rt.local_rays
         alg_bytes = 16 * local + (32 * local if ray_source == "buffer" else 0) + 320 * len(objs) + 64 * len(lights)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic = None
-        tf = ROOT / "profiles" / f"traffic_{args.workload}.json"
-        if tf.exists() and world == 1:
-            try:
-                traffic = json.loads(tf.read_text())["hbm_bytes_per_launch"]
-            except Exception:
-                traffic = None
+        prof, prof_why = (frame_profile(args.workload) if world == 1 else (None, "counters are collected on one GPU"))
+        traffic = prof["hbm_bytes_per_launch"] if prof else None
         out = {
             "metric": "Mrays/s (primary+reflect+shadow) at 4096x4096, 1/2/4/8 GPU; max RGB diff vs ref",
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": steps, "warmup": warmup,
@@ -319,48 +342,61 @@ def main():
                        "partition": f"row-tiles of {args.tile_rows} rows, interleaved over {world} rank(s), gather to rank 0"
                        if world > 1 else "single GPU", "arithmetic": "fused (fma where the OpenCL front-end marks fmuladd)",
                        "literal": bool(args.literal)},
+            # `value` counts the rays the REFERENCE semantics trace for the frame (R_ref); what this backend
+            # actually traced after its exact eliminations is rays_traced / mrays_traced_per_s - quote that one against
+            # other raytracers
             "rays_reference": rays_ref, "rays_traced": rays_act, "hit_pixels": hit_pixels,
             "mrays_traced_per_s": rays_act * steps / elapsed / 1e6,
+            "library_sha16": library_sha16(),
         }
         hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes}
+        if prof:
+            # what the counters saw leave the L2s for the fabric (Infinity Cache hits included), against the compulsory bytes
+            hbm["traffic_over_algorithmic"] = traffic / alg_bytes
+            hbm["fabric_GBps"] = traffic / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else None
+            hbm["fabric_frac_of_hbm_peak"] = traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms > 0 else None
+            hbm["traffic_source"] = f"profiles/frame_{args.workload}.json (rocprofv3 PMC, library {prof['lib_sha16']})"
+        else:
+            hbm["traffic_unavailable"] = prof_why
         if args.workload.startswith("cfg4"):
-            # 100k-object frames are compute bound by four orders of magnitude in bytes: the roofline
-            # that can bind the traversal kernels is the FP32 vector ALU. achieved = counted ray-object tests x 35
-            # lane-instructions (the minimal exact ray-sphere rejection test) / device time of all kernels of the frame;
-            # peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz per GPU.
+            # SURVEY.md 8d's figure for 100k-object frames: counted ray-object tests x 35 lane-instructions (the minimal exact
+            # ray-sphere rejection test) / device time of all kernels of the frame, against 256 CU x 4 SIMD x 32 lanes x 2.4 GHz.
             tests = int(tests_total)
             valu = tests * SPHERE_TEST_LANE_OPS / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0
             culled = not (args.no_grid or args.literal)
             out["roofline"] = {"bound": "valu", "achieved": valu / 1e12, "peak": VALU_PEAK_LANE_OPS * world / 1e12,
-                               "unit": "T lane-instr/s", "frac": valu / (VALU_PEAK_LANE_OPS * world), "traffic": None,
+                               "unit": "T lane-instr/s", "frac": valu / (VALU_PEAK_LANE_OPS * world), "traffic": traffic,
                                "kernel": ("rt::wf_trace_grid_persistent<closest|any> + rt::wf_trace_primary_tiles" if culled else
                                           "rt::wf_trace_closest + rt::wf_trace_any_slice") + " (+ wf_resume, wf_begin)",
                                "kernel_ms": kernel_ms, "object_tests": tests,
                                "tests_per_s": tests / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0, "hbm": hbm}
-            isf = ROOT / "profiles" / f"issue_{args.workload}.json"
-            if culled and world == 1 and isf.exists():
-                # what the grid path IS bound by: issue of vector instructions (PMC count of one frame, tools/pmc_issue.sh,
-                # divided by the live kernel time of this run; ~4 cycles per wave-instruction for this instruction mix)
-                try:
-                    isd = json.loads(isf.read_text())
-                    rate = isd["valu_wave_instructions"] / (kernel_ms * 1e-3)
-                    out["roofline"]["valu_issue"] = {
-                        "bound": "valu_issue", "achieved": rate / 1e9, "peak": isd["peak_valu_wave_instructions_per_s"] / 1e9,
-                        "unit": "G wave-instr/s", "frac": rate / isd["peak_valu_wave_instructions_per_s"],
-                        "lanes_per_instruction": isd["lanes_per_valu_instruction"],
-                        "waves_waiting_frac": isd["wait_quad_cycles"] / isd["wave_quad_cycles"],
-                        "source": "profiles/issue_cfg4.json (rocprofv3 --pmc SQ_INSTS_VALU ..., one frame) / live kernel time"}
-                except Exception:
-                    pass
+            if culled and prof:
+                # the issue-slot view and the per-kernel memory view of the same frame, from the stamped counter file
+                rate = prof["valu_wave_instructions"] / (kernel_ms * 1e-3)
+                out["roofline"]["valu_issue"] = {
+                    "bound": "valu_issue", "achieved": rate / 1e9, "peak": prof["peak_valu_wave_instructions_per_s"] / 1e9,
+                    "unit": "G wave-instr/s", "frac": rate / prof["peak_valu_wave_instructions_per_s"],
+                    "peak_note": prof.get("peak_note"),
+                    "lanes_per_instruction": prof["lanes_per_valu_instruction"],
+                    "waves_waiting_frac": prof["wait_quad_cycles"] / prof["wave_quad_cycles"],
+                    "salu_per_valu": prof["salu_wave_instructions"] / max(prof["valu_wave_instructions"], 1.0),
+                    "source": f"profiles/frame_{args.workload}.json: PMC instruction count of one frame / live kernel time"}
+                out["roofline"]["per_kernel"] = {
+                    k: {"launches": v["launches"], "ms": v["ms"], "traffic_bytes": v["traffic_bytes"],
+                        "traffic_frac_of_hbm_peak": v["traffic_frac_of_hbm_peak"], "valu_issue_frac": v["valu_issue_frac"],
+                        "lanes_per_valu_instruction": v["lanes_per_valu_instruction"]}
+                    for k, v in prof["kernels"].items()}
+            elif culled:
+                out["roofline"]["counters_unavailable"] = prof_why
             if culled:
-                out["roofline"]["note"] = ("default path = conservative grid culling: %.1f exact ray-object tests per traced ray instead of %d "
-                                           "(each preceded by ~5 16-byte bounding-sphere pre-tests and ~5 cell steps); the walk is bound by the "
-                                           "issue of its bookkeeping instructions and by L2 latency, not by the 35-instruction tests this "
-                                           "roofline counts, so its fraction is small by design (valu_issue = the issue-slot view of the same "
-                                           "frame) - the brute-force traversal kernels it replaces, which ARE bound by those tests, are "
-                                           "reported in brute_force") % (
-                                               tests / max(rays_act, 1), len(objs))
+                out["roofline"]["note"] = (
+                    "default path = conservative grid culling: %.1f exact ray-object tests per traced ray instead of %d, so by "
+                    "SURVEY 8d's definition (35 lane-instructions x executed tests) the frame sits at a small fraction of the VALU "
+                    "roofline; what the kernels are really limited by is in valu_issue (issue slots, lanes per instruction) and in "
+                    "hbm / per_kernel (bytes the L2s pulled through the fabric vs the compulsory bytes). The brute-force traversal "
+                    "kernels the grid replaces - which ARE bound by those tests - are measured in brute_force") % (
+                        tests / max(rays_act, 1), len(objs))
                 if world == 1 and not args.no_extra:
                     out["roofline"]["brute_force"] = measure_brute_force_window(local_rank, 4096)
         elif args.workload == "cfg5":

@@ -75,6 +75,9 @@ struct rt_context {
     rt::ScreenTiles tiles = {};
     bool tiles_dirty = true;
     bool has_triangles = false;             // type-2 records (extension): only the grid path knows them
+    int nan_winner = -1;                    // the last sphere / box of the scene decides what a NaN ray ends with (rt_device.h)
+    bool nan_winner_sphere = false;
+    bool forced_literal = false;            // a degenerate instance switched the context to RT_FLAG_LITERAL (rt_create)
     bool affine_w = true;                   // every mv / mvInverse has bottom row (0,0,0,1) exactly
     bool primary_w_one = true;              // every uploaded primary ray has start.w == 1
     double origin_lo[3] = {0, 0, 0}, origin_hi[3] = {0, 0, 0};  // box of the primary ray origins
@@ -88,7 +91,7 @@ struct rt_context {
     hipEvent_t ev_begin[kTimingSlots];
     hipEvent_t ev_end[kTimingSlots];
     uint32_t ev_count = 0;   // launches recorded since the last rt_timing_reset
-    bool ev_created = false;
+    uint32_t ev_begin_made = 0, ev_end_made = 0;  // events created so far (rt_destroy frees a partial set too)
     float last_ms = 0.f;
 
     std::string error;
@@ -106,6 +109,31 @@ int fail_hip(rt_context* ctx, hipError_t e, const char* what) {
     return fail(ctx, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP,
                 std::string(what) + ": " + hipGetErrorString(e));
 }
+
+// The C ABI must not change the calling thread's current HIP device (the caller is usually a host framework with
+// its own idea of it): every entry point that needs the context's device switches to it through this guard, which
+// restores the caller's device on every exit path.
+struct DeviceGuard {
+    int saved = -1;
+    bool ok = true;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&saved) != hipSuccess) saved = -1;
+        if (saved != device) {
+            err = hipSetDevice(device);
+            ok = (err == hipSuccess);
+        }
+    }
+    ~DeviceGuard() {
+        int now = -1;
+        if (saved >= 0 && hipGetDevice(&now) == hipSuccess && now != saved) (void)hipSetDevice(saved);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define RT_DEVICE(ctx)                                                       \
+    DeviceGuard device_guard_((ctx)->device);                                \
+    if (!device_guard_.ok) return fail_hip((ctx), device_guard_.err, "hipSetDevice")
 
 #define RT_HIP(ctx, call)                                           \
     do {                                                            \
@@ -410,8 +438,8 @@ int ensure_wavefront(rt_context* c) {
         RT_HIP(c, hipMalloc((void**)&b.q_any[i], rt::wavefront_queue_bytes(n)));
         RT_HIP(c, hipMalloc((void**)&b.q_slice[i], rt::wavefront_queue_bytes(n)));
     }
-    RT_HIP(c, hipMalloc((void**)&b.counts, 8 * sizeof(uint32_t)));  // 4 queue counters + 2 run-ticket counters
-    RT_HIP(c, hipHostMalloc((void**)&b.h_counts, 4 * sizeof(uint32_t), hipHostMallocDefault));
+    RT_HIP(c, hipMalloc((void**)&b.counts, rt::wavefront_counter_bytes()));  // device-side round state + run-ticket counters
+    RT_HIP(c, hipHostMalloc((void**)&b.h_counts, 16 * sizeof(uint32_t), hipHostMallocDefault));
     RT_HIP(c, hipStreamCreateWithFlags(&b.side_stream, hipStreamNonBlocking));
     RT_HIP(c, hipEventCreateWithFlags(&b.ev_fork, hipEventDisableTiming));
     RT_HIP(c, hipEventCreateWithFlags(&b.ev_join, hipEventDisableTiming));
@@ -443,6 +471,8 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     p.scene.n_objs = c->n_objs;
     p.scene.n_lights = c->n_lights;
     p.scene.literal = (c->flags & RT_FLAG_LITERAL) ? 1u : 0u;
+    p.scene.nan_winner = c->nan_winner;
+    p.scene.nan_winner_sphere = c->nan_winner_sphere ? 1u : 0u;
     p.rays = c->pinhole ? nullptr : c->d_rays;
     p.n_rays = c->n_rays;
     p.n_local = c->n_local;
@@ -477,7 +507,7 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     p.aux_index = c->aux_index;
     p.counters = c->d_counters;
 
-    RT_HIP(c, hipSetDevice(c->device));
+    RT_DEVICE(c);
     if (p.tile_cull && c->rects_dirty) {  // screen rectangles of the bounding spheres for this camera
         std::vector<float4> rects(c->n_objs);
         for (uint32_t i = 0; i < c->n_objs; ++i)
@@ -487,13 +517,9 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
         RT_HIP(c, hipStreamSynchronize(stream));  // `rects` is pageable host memory
         c->rects_dirty = false;
     }
-    if (count) RT_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters), stream));
-    const uint32_t slot = c->ev_count % kTimingSlots;
-    RT_HIP(c, hipEventRecord(c->ev_begin[slot], stream));
-    hipError_t e;
     c->last_wavefront = use_wavefront(c);
     c->last_rounds = 0;
-    if (c->last_wavefront) {
+    if (c->last_wavefront) {  // one-time host-side set-up (buffers, per-camera screen tiles) stays outside the timed region
         int rc = ensure_wavefront(c);
         if (rc) return rc;
         if (c->tiles_dirty) {
@@ -501,10 +527,13 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
             if (rc) return rc;
         }
         c->wf.tiles = c->tiles;
-        e = rt::launch_wavefront(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, c->wf, stream, &c->last_rounds);
-    } else {
-        e = rt::launch_render(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, stream);
     }
+    if (count) RT_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(rt::Counters), stream));
+    const uint32_t slot = c->ev_count % kTimingSlots;
+    RT_HIP(c, hipEventRecord(c->ev_begin[slot], stream));
+    hipError_t e;
+    if (c->last_wavefront) e = rt::launch_wavefront(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, c->wf, stream, &c->last_rounds);
+    else e = rt::launch_render(p, c->kernel, !(c->flags & RT_FLAG_UNFUSED), count, stream);
     if (e != hipSuccess) return fail_hip(c, e, "kernel launch");
     RT_HIP(c, hipEventRecord(c->ev_end[slot], stream));
     c->ev_count += 1;
@@ -527,10 +556,16 @@ int build_screen_tiles(rt_context* c, hipStream_t stream) {
     const uint32_t n = c->n_objs;
     const double half_w = (double)((float)c->width / 2.0f), half_h = (double)((float)c->height / 2.0f), H = (double)c->height;
     const double inf = std::numeric_limits<double>::infinity();
-    std::vector<uint32_t> start(n_tiles + 1, 0), entries, fill;
+    std::vector<uint32_t> start(n_tiles + 1, 0), entries, fill, global;
     struct Range { int x0, x1, y0, y1; };
     std::vector<Range> rng(n);
-    size_t total = 0;
+    // (object, tile) pairs are counted in 64 bits against the budget BEFORE any per-tile loop runs: an object whose
+    // sphere reaches the camera plane projects onto the whole screen (131 072 tiles at 8192^2), and a few ten
+    // thousand of those would wrap a 32-bit prefix sum. Such objects go to a per-camera global list that every tile
+    // wave tests (at most kMaxGlobal of them; beyond that the grid walk is the better tool for primary rays too).
+    constexpr size_t kMaxGlobal = 64;
+    const uint64_t budget = 256ull * n + 4096ull;
+    uint64_t total = 0;
     for (uint32_t i = 0; i < n; ++i) {
         const double r = c->h_grid_spheres[4 * i + 3];
         Range& q = rng[i];
@@ -544,31 +579,44 @@ int build_screen_tiles(rt_context* c, hipStream_t stream) {
         const double cx0 = std::max(0.0, std::floor(c0)), cx1 = std::min((double)c->width - 1, std::ceil(c1));
         const double ry0 = std::max(0.0, std::floor(r0)), ry1 = std::min((double)c->height - 1, std::ceil(r1));
         if (cx0 > cx1 || ry0 > ry1) continue;
-        q.x0 = (int)(cx0 / 64); q.x1 = (int)(cx1 / 64); q.y0 = (int)(ry0 / 8); q.y1 = (int)(ry1 / 8);
+        const int x0 = (int)(cx0 / 64), x1 = (int)(cx1 / 64), y0 = (int)(ry0 / 8), y1 = (int)(ry1 / 8);
+        const uint64_t covered = (uint64_t)(x1 - x0 + 1) * (uint64_t)(y1 - y0 + 1);
+        if (covered == (uint64_t)n_tiles && n_tiles > 1) {  // the whole screen
+            if (global.size() >= kMaxGlobal) return RT_OK;
+            global.push_back(i);
+            continue;
+        }
+        total += covered;
+        if (total > budget) return RT_OK;  // objects cover most of the screen: the grid walk is the better tool
+        q.x0 = x0; q.x1 = x1; q.y0 = y0; q.y1 = y1;
         for (int y = q.y0; y <= q.y1; ++y)
             for (int x = q.x0; x <= q.x1; ++x) start[(size_t)y * tx + x + 1] += 1;
     }
-    for (size_t k = 0; k < n_tiles; ++k) start[k + 1] += start[k];
-    total = start[n_tiles];
-    if (total > 256ull * n + 4096) return RT_OK;  // objects cover most of the screen: the grid walk is the better tool
-    entries.assign(total, 0);
+    for (size_t k = 0; k < n_tiles; ++k) start[k + 1] += start[k];  // total <= budget < 2^32 (n_objs is a uint32, budget clamps below)
+    if (total > 0xfffffff0ull) return RT_OK;
+    entries.assign((size_t)total + global.size(), 0);
     fill.assign(start.begin(), start.end() - 1);
     for (uint32_t i = 0; i < n; ++i) {
         const Range& q = rng[i];
         for (int y = q.y0; y <= q.y1; ++y)
             for (int x = q.x0; x <= q.x1; ++x) entries[fill[(size_t)y * tx + x]++] = i;
     }
+    for (size_t k = 0; k < n_tiles; ++k)
+        if (fill[k] != start[k + 1]) return fail(c, RT_ERR_STATE, "internal: screen-tile fill does not match its count");
+    for (size_t k = 0; k < global.size(); ++k) entries[(size_t)total + k] = global[k];  // the global list sits behind the last tile's
     if (c->d_tile_start) (void)hipFree(c->d_tile_start);
     if (c->d_tile_entries) (void)hipFree(c->d_tile_entries);
     c->d_tile_start = c->d_tile_entries = nullptr;
     RT_HIP(c, hipMalloc((void**)&c->d_tile_start, sizeof(uint32_t) * (n_tiles + 1)));
-    RT_HIP(c, hipMalloc((void**)&c->d_tile_entries, sizeof(uint32_t) * (total + 1)));
+    RT_HIP(c, hipMalloc((void**)&c->d_tile_entries, sizeof(uint32_t) * (entries.size() + 1)));
     RT_HIP(c, hipMemcpyAsync(c->d_tile_start, start.data(), sizeof(uint32_t) * (n_tiles + 1), hipMemcpyHostToDevice, stream));
-    if (total) RT_HIP(c, hipMemcpyAsync(c->d_tile_entries, entries.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice, stream));
+    if (!entries.empty()) RT_HIP(c, hipMemcpyAsync(c->d_tile_entries, entries.data(), sizeof(uint32_t) * entries.size(), hipMemcpyHostToDevice, stream));
     RT_HIP(c, hipStreamSynchronize(stream));
     c->tiles.tile_start = c->d_tile_start;
     c->tiles.entries = c->d_tile_entries;
     c->tiles.tiles_x = tx;
+    c->tiles.global_begin = (uint32_t)total;
+    c->tiles.n_global = (uint32_t)global.size();
     c->tiles.enabled = 1u;
     return RT_OK;
 }
@@ -705,6 +753,11 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     const size_t n_cells = (size_t)dim[0] * dim[1] * dim[2];
     std::vector<uint32_t> start(n_cells + 1, 0);
     size_t total = 0;
+    // (object, cell) pairs: counted in 64 bits against the budget as the first pass goes, and an object's BOX of cells
+    // is checked before its cells are visited - many large overlapping objects must neither wrap the 32-bit prefix
+    // sums nor cost billions of iterations before the grid is given up
+    const uint64_t entry_budget = std::min<uint64_t>((c->has_triangles ? 1024ull : 64ull) * n + 1024ull, 0x7fffffffull);
+    uint64_t counted = 0;
     std::vector<uint32_t> entries, fill;
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
@@ -715,6 +768,11 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
             if (!(rg[i] >= 0) || !std::isfinite(rg[i])) continue;
             int x0, x1, y0, y1, z0, z1;
             range(i, 0, x0, x1); range(i, 1, y0, y1); range(i, 2, z0, z1);
+            if (pass == 0) {
+                if (x1 < x0 || y1 < y0 || z1 < z0) continue;
+                const uint64_t box_cells = (uint64_t)(x1 - x0 + 1) * (uint64_t)(y1 - y0 + 1) * (uint64_t)(z1 - z0 + 1);
+                if (box_cells > 8ull * entry_budget) return RT_OK;  // the sphere fills >= ~half of its box: far over budget on its own
+            }
             // of the cells its box touches, only those the registration SPHERE reaches (distance from the centre to
             // the cell's box <= radius, cell walls taken from the kernels' float origin / edge, radius already
             // holding 0.01 cell of slack): a quarter fewer entries for spheres that are small against a cell
@@ -733,16 +791,16 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
                     for (int x = x0; x <= x1; ++x) {
                         if (dyz2 + gap2(0, x) > r2) continue;
                         const size_t cidx = ((size_t)z * dim[1] + y) * dim[0] + x;
-                        if (pass == 0) start[cidx + 1] += 1;
+                        if (pass == 0) { start[cidx + 1] += 1; ++counted; }
                         else entries[fill[cidx]++] = i;
                     }
                 }
             }
+            if (pass == 0 && counted > entry_budget) return RT_OK;  // objects too large for this cell size: not worth it
         }
         if (pass == 0) {
             for (size_t k = 0; k < n_cells; ++k) start[k + 1] += start[k];
             total = start[n_cells];
-            if (total > (c->has_triangles ? 1024ull : 64ull) * n + 1024) return RT_OK;  // objects too large for this cell size: not worth it
         } else {
             RT_HIP(c, hipMalloc((void**)&c->d_grid_entries, sizeof(uint32_t) * (total + 1)));
             RT_HIP(c, hipMalloc((void**)&c->d_grid_always, sizeof(uint32_t) * (always.size() + 1)));
@@ -812,9 +870,6 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     g.always = c->d_grid_always;
     g.n_always = (uint32_t)always.size();
     g.has_triangles = c->has_triangles ? 1u : 0u;
-    g.nan_winner = -1;
-    for (uint32_t i = n; i-- > 0;)
-        if (objs[i].type <= 1u) { g.nan_winner = (int)i; break; }
     g.pretest_alpha = std::nextafter((float)(6e-6 * K2 + 8e-6), std::numeric_limits<float>::infinity());
     g.enabled = 1u;
     c->h_grid_spheres.resize(4 * (size_t)n);
@@ -875,13 +930,15 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         if (e2_ != hipSuccess) { rc = fail_hip(c, e2_, #call); return bail(rc); } \
     } while (0)
 
-    RT_TRY(hipSetDevice(device));
+    DeviceGuard guard(device);  // restores the caller's current device on every return below
+    if (!guard.ok) { rc = fail_hip(c, guard.err, "hipSetDevice"); return bail(rc); }
     RT_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (uint32_t i = 0; i < kTimingSlots; ++i) {
         RT_TRY(hipEventCreate(&c->ev_begin[i]));
+        c->ev_begin_made = i + 1;
         RT_TRY(hipEventCreate(&c->ev_end[i]));
+        c->ev_end_made = i + 1;
     }
-    c->ev_created = true;
     RT_TRY(hipMalloc((void**)&c->d_counters, sizeof(rt::Counters)));
 
     {
@@ -929,11 +986,23 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
 
     for (uint32_t i = 0; i < n_objs; ++i)
         if (static_cast<const rt_object_data*>(objs)[i].type == 2u) { c->has_triangles = true; break; }
+    for (uint32_t i = n_objs; i-- > 0;) {
+        const uint32_t ty = static_cast<const rt_object_data*>(objs)[i].type;
+        if (ty <= 1u) { c->nan_winner = (int)i; c->nan_winner_sphere = (ty == 0u); break; }
+    }
     for (uint32_t i = 0; i < n_objs && c->affine_w; ++i) {
         const rt_object_data& o = static_cast<const rt_object_data*>(objs)[i];
         if (o.type == 2u) continue;  // vertices, not matrices
         c->affine_w = o.mv[3] == 0.f && o.mv[7] == 0.f && o.mv[11] == 0.f && o.mv[15] == 1.f && o.mvInverse[3] == 0.f &&
                       o.mvInverse[7] == 0.f && o.mvInverse[11] == 0.f && o.mvInverse[15] == 1.f;
+    }
+    // An instance that can produce a NaN hit time for a FINITE ray (non-finite or singular rows x,y,z of mvInverse:
+    // a scale of 0, garbage) makes the reference's result depend on the ORDER its loop meets the objects in - a NaN
+    // time overwrites and is overwritten. The exact eliminations (any-hit shadow rays on a size-sorted stream, the
+    // grid) assume finite times, so such scenes are rendered the literal way: every ray, every object, in order.
+    for (uint32_t i = 0; i < n_objs && !(c->flags & RT_FLAG_LITERAL); ++i) {
+        const rt_object_data& o = static_cast<const rt_object_data*>(objs)[i];
+        if (o.type <= 1u && !std::isfinite(object_bound(o).r)) { c->flags |= RT_FLAG_LITERAL; c->forced_literal = true; }
     }
     if (rays && n_rays) {
         const rt_ray* r = static_cast<const rt_ray*>(rays);
@@ -1012,12 +1081,14 @@ int rt_set_aux_device(rt_context* c, void* d_hit_t, void* d_hit_index) {
 int rt_render_device(rt_context* c, void* d_out, void* hip_stream) {
     if (!c) return RT_ERR_INVALID_ARGUMENT;
     if (!d_out && c->n_local) return fail(c, RT_ERR_INVALID_ARGUMENT, "d_out is NULL");
-    hipStream_t s = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->stream;
-    return do_launch(c, d_out, s, false);
+    // NULL is the legacy default stream - NOT the context's private stream: a caller that passes its framework's
+    // "current stream" handle (0 for torch's default stream) gets a render that is ordered with its own work
+    return do_launch(c, d_out, static_cast<hipStream_t>(hip_stream), false);
 }
 
 int rt_render(rt_context* c, const float** out) {
     if (!c || !out) return RT_ERR_INVALID_ARGUMENT;
+    RT_DEVICE(c);
     int rc = ensure_out(c);
     if (rc) return rc;
     rc = ensure_host_out(c);
@@ -1038,7 +1109,7 @@ int rt_render_aux(rt_context* c, float* hit_t, int32_t* hit_index) {
     float* d_t = nullptr;
     int32_t* d_i = nullptr;
     const size_t n = (size_t)c->n_local;
-    RT_HIP(c, hipSetDevice(c->device));
+    RT_DEVICE(c);
     if (hit_t) RT_HIP(c, hipMalloc((void**)&d_t, n ? n * 4 : 4));
     if (hit_index) {
         hipError_t e = hipMalloc((void**)&d_i, n ? n * 4 : 4);
@@ -1060,6 +1131,7 @@ int rt_render_aux(rt_context* c, float* hit_t, int32_t* hit_index) {
 
 int rt_count_rays(rt_context* c) {
     if (!c) return RT_ERR_INVALID_ARGUMENT;
+    RT_DEVICE(c);
     int rc = ensure_out(c);
     if (rc) return rc;
     rc = do_launch(c, c->d_out, c->stream, true);
@@ -1083,6 +1155,7 @@ int rt_count_rays(rt_context* c) {
 
 int rt_get_stats(rt_context* c, rt_stats_t* s) {
     if (!c || !s) return RT_ERR_INVALID_ARGUMENT;
+    RT_DEVICE(c);
     if (c->ev_count) {
         const uint32_t slot = (c->ev_count - 1) % kTimingSlots;
         RT_HIP(c, hipEventSynchronize(c->ev_end[slot]));
@@ -1110,6 +1183,7 @@ int rt_timing_reset(rt_context* c) {
 
 int rt_timing_summary(rt_context* c, double* sum_ms, uint32_t* launches) {
     if (!c || !sum_ms || !launches) return RT_ERR_INVALID_ARGUMENT;
+    RT_DEVICE(c);
     const uint32_t n = c->ev_count < kTimingSlots ? c->ev_count : kTimingSlots;
     double total = 0.0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -1125,7 +1199,7 @@ int rt_timing_summary(rt_context* c, double* sum_ms, uint32_t* launches) {
 
 void rt_destroy(rt_context* c) {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_pairs) (void)hipFree(c->d_pairs);
     if (c->d_shadow_pairs) (void)hipFree(c->d_shadow_pairs);
@@ -1144,12 +1218,8 @@ void rt_destroy(rt_context* c) {
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->d_counters) (void)hipFree(c->d_counters);
     free_wavefront(c);
-    if (c->ev_created) {
-        for (uint32_t i = 0; i < kTimingSlots; ++i) {
-            (void)hipEventDestroy(c->ev_begin[i]);
-            (void)hipEventDestroy(c->ev_end[i]);
-        }
-    }
+    for (uint32_t i = 0; i < c->ev_begin_made; ++i) (void)hipEventDestroy(c->ev_begin[i]);
+    for (uint32_t i = 0; i < c->ev_end_made; ++i) (void)hipEventDestroy(c->ev_end[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -390,7 +390,10 @@ __device__ __forceinline__ bool occludes(uint32_t type, float sx, float sy, floa
     bool cand = false;
     if (type == 0u) cand = sphere_candidate<FUSED>(sx, sy, sz, dx, dy, dz, t);
     else if (type == 1u) cand = box_candidate(sx, sy, sz, dx, dy, dz, t);
-    return cand && t < 1.f;
+    // `!(t >= 1)`, not `t < 1`: a NaN time (a shadow ray with a NaN in it - a light exactly at the hit point, a zero
+    // directional light) is accepted by every sphere / box of the reference's loop, the final time is NaN, and its
+    // `time >= 1 || time < 0` (:229) then reports the light as blocked
+    return cand && !(t >= 1.f);
 }
 
 template <bool FUSED>
@@ -564,6 +567,33 @@ __device__ __forceinline__ void materialise(const HotObject* __restrict__ hot, c
     h.index = index;
 }
 
+// ---- rays with a NaN in them ---------------------------------------------------------------------------------------
+// Every rejection in the reference's tests is a comparison, and a NaN fails them all, so its loop does not skip
+// objects for such a ray - what it ends with depends only on the LAST sphere / box of the scene (types >= 2 never hit):
+//  * a NaN reaches the object-space DIRECTION of every object (any NaN in the view-space direction: 0 * NaN = NaN in
+//    every row of transform()): every sphere and every box accepts with time = NaN -> the last one leaves NaN;
+//  * the direction is exactly (0,0,0) and the start is NaN - the shadow ray of a light AT the hit point or of a zero
+//    directional light, start = P + 0.01 * normalize(0) (.cl:195-205): a sphere accepts with NaN, a box takes the
+//    `dir == 0` branch of all three slabs (:36-43; copysign(NaN, .) == NaN is false) -> tHit = MAX_FLOAT, accepted iff
+//    the time so far is NaN -> a last sphere leaves NaN, a last box leaves MAX_FLOAT.
+// Shadow rays (built from finite scene data) can only be of these two kinds; a NaN start with a finite non-zero
+// direction (possible for caller-made primary rays) is outside this closed form and outside the grid path's domain.
+// Rays with an infinite component are not classified (the outcome then depends on each object's matrix).
+// The brute-force loops need none of this for closest-hit rays (they run the reference's loop in order); the order-free
+// parts - any-hit shadow tests, the grid - ask here first.
+enum : int { kNanRayNone = 0, kNanRayTimeNaN = 1, kNanRayTimeMax = 2 };
+__device__ __forceinline__ int nan_ray_outcome(const Ray& ray, int nan_winner, uint32_t winner_is_sphere) {
+    const float s = ((ray.sx + ray.sy) + ray.sz) + ((ray.dx + ray.dy) + ray.dz);
+    if (s == s) return kNanRayNone;  // no NaN (and no inf - inf)
+    const float inf = __builtin_inff();
+    if (__builtin_fabsf(ray.sx) == inf || __builtin_fabsf(ray.sy) == inf || __builtin_fabsf(ray.sz) == inf ||
+        __builtin_fabsf(ray.dx) == inf || __builtin_fabsf(ray.dy) == inf || __builtin_fabsf(ray.dz) == inf)
+        return kNanRayNone;
+    if (nan_winner < 0) return kNanRayTimeMax;  // nothing in the scene accepts anything
+    const bool zero_dir = ray.dx == 0.f && ray.dy == 0.f && ray.dz == 0.f;
+    return (zero_dir && !winner_is_sphere) ? kNanRayTimeMax : kNanRayTimeNaN;
+}
+
 // ---- shading -----------------------------------------------------------------------------------------------
 struct Scene {
     const HotPair* __restrict__ pairs;   // traversal stream, ceil(n_objs / 2) records
@@ -576,6 +606,8 @@ struct Scene {
     uint32_t n_objs;
     uint32_t n_lights;
     uint32_t literal;  // RT_FLAG_LITERAL
+    int nan_winner;            // index of the LAST sphere / box of the scene (-1: none) and whether it is a sphere:
+    uint32_t nan_winner_sphere;  // what the reference's loop ends with for a ray with a NaN in it (nan_ray_outcome)
 };
 
 // secondary rays (shadow / reflection; direction.w == 0): pair stream in the wavefront kernels, one object at a
@@ -635,6 +667,10 @@ __device__ __forceinline__ void light_geometry(const LightRec& L, const HitRec& 
 template <bool FUSED, bool COUNT>
 __device__ __forceinline__ bool light_visible(const Scene& S, const Ray& shadow, Counters& ctr) {
     if constexpr (COUNT) ctr.traced += 1;
+    if (!S.literal) {  // the any-hit test is order-free: a NaN shadow ray's outcome is not (`time >= 1 || time < 0`, :229)
+        const int k = nan_ray_outcome(shadow, S.nan_winner, S.nan_winner_sphere);
+        if (k != kNanRayNone) return k == kNanRayTimeMax;
+    }
     if (S.literal) {
         float T = kMaxFloat;
         int idx = -1;

@@ -56,8 +56,6 @@ struct GridDesc {
     uint32_t n_always;
     float pretest_alpha;   // distance-dependent term of the pre-test radius (misses_bounding_sphere)
     uint32_t has_triangles;  // the scene holds type-2 records (selects the kernel variants that know them)
-    int nan_winner;        // what the reference's loop returns for a NaN ray: every sphere / box "accepts" it with
-                           // t = NaN (all its rejections are comparisons), so the LAST one wins; -1: none in the scene
     uint32_t enabled;
 };
 
@@ -66,6 +64,7 @@ struct ScreenTiles {
     const uint32_t* __restrict__ tile_start;  // tiles_x * tiles_y + 1 offsets
     const uint32_t* __restrict__ entries;     // object indices, ascending inside a tile
     uint32_t tiles_x;                         // tiles are 64 pixels wide, 8 rows tall
+    uint32_t global_begin, n_global;          // entries[global_begin ..): objects whose projection is the whole screen
     uint32_t enabled;
 };
 
@@ -145,14 +144,10 @@ __device__ __forceinline__ bool lane_candidate(const HotObject* __restrict__ o, 
     return false;
 }
 
-// A ray with a NaN in it (and no infinity, which would make the outcome depend on the object) walks no cells; the
-// consumer of the result patches in what the reference's loop returns for it (closest_result, rt_wavefront.hip).
-// Shadow rays: NaN < 1 is false, nothing occludes - which is what the walk reports for a ray that misses the grid.
-__device__ __forceinline__ bool ray_has_nan(const Ray& ray) {
-    const float s = ((ray.sx + ray.sy) + ray.sz) + ((ray.dx + ray.dy) + ray.dz);
-    return !(s == s) && !(__builtin_fabsf(ray.sx) == __builtin_inff() || __builtin_fabsf(ray.sy) == __builtin_inff() ||
-                          __builtin_fabsf(ray.sz) == __builtin_inff() || __builtin_fabsf(ray.dx) == __builtin_inff() ||
-                          __builtin_fabsf(ray.dy) == __builtin_inff() || __builtin_fabsf(ray.dz) == __builtin_inff());
+// A ray with a NaN in it walks no cells; what the reference's loop ends with for it is nan_ray_outcome() (rt_device.h),
+// patched in where the walk's result is produced (shadow rays) or consumed (closest_result, rt_wavefront.hip).
+__device__ __forceinline__ bool nan_shadow_blocked(const Scene& S, const Ray& ray) {
+    return nan_ray_outcome(ray, S.nan_winner, S.nan_winner_sphere) == kNanRayTimeNaN;
 }
 
 // 3-D DDA state for one ray. All of it is plain fp32 bookkeeping about WHICH cells to look at; it never feeds
@@ -326,17 +321,18 @@ __device__ __forceinline__ void closest_hit_grid(const GridDesc& g, const HotObj
 // Any hit with t < 1 through the grid, one thread per ray (the tail of a frame: wf_finish). Same answer as the
 // brute-force any-hit loops: every candidate that can occlude is registered in a cell the walk visits.
 template <bool FUSED>
-__device__ __forceinline__ bool any_hit_grid(const GridDesc& g, const HotObject* __restrict__ hot, const Ray& ray, uint32_t& tested) {
+__device__ __forceinline__ bool any_hit_grid(const GridDesc& g, const Scene& S, const Ray& ray, uint32_t& tested) {
+    const HotObject* __restrict__ hot = S.hot;
     for (uint32_t a = 0; a < g.n_always; ++a) {
         float t;
         bool sphere;
         ++tested;
-        if (lane_candidate<FUSED, true>(hot + (int)g.always[a], ray, t, sphere) && t < 1.f) return true;
+        if (lane_candidate<FUSED, true>(hot + (int)g.always[a], ray, t, sphere) && !(t >= 1.f)) return true;
     }
     const float len = __builtin_sqrtf(ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz);
     const float slack = len > 0.f ? kWalkSlackCells * g.cell / len : 3.0e38f;
     Walk w = walk_begin(g, ray, 1.0f + slack);
-    if (!w.alive) return false;
+    if (!w.alive) return nan_shadow_blocked(S, ray);  // off the grid: nothing in the way - unless the ray is a NaN ray
     for (;;) {
         const uint32_t c = ((uint32_t)w.iz * (uint32_t)g.ny + (uint32_t)w.iy) * (uint32_t)g.nx + (uint32_t)w.ix;
         const uint2 range = g.cell_range[c];
@@ -344,7 +340,7 @@ __device__ __forceinline__ bool any_hit_grid(const GridDesc& g, const HotObject*
         for (uint32_t e = range.x; e < range.x + range.y; ++e) {
             float t;
             bool sphere;
-            if (lane_candidate<FUSED, true>(hot + (int)g.entries[e], ray, t, sphere) && t < 1.f) return true;
+            if (lane_candidate<FUSED, true>(hot + (int)g.entries[e], ray, t, sphere) && !(t >= 1.f)) return true;
         }
         if (!walk_next(g, w)) break;
         if (w.t_enter > 1.0f + slack) break;

@@ -42,15 +42,17 @@ struct WavefrontBuffers {
     const HotPair* shadow_pairs = nullptr;         // size-sorted pair stream (owned by the context)
     GridDesc grid = {};                            // conservative grid (owned by the context); enabled = 0 -> brute force
     ScreenTiles tiles = {};                        // per-screen-tile object lists for pinhole primary rays
-    uint32_t* counts = nullptr;                    // 4 queue counters + 2 run-ticket counters of the grid walk
-    uint32_t* h_counts = nullptr;                  // 4 x uint32 pinned host mirror
+    uint32_t* counts = nullptr;                    // device-side round state (queue lengths, hand-over flags) + run-ticket counters
+    uint32_t* h_counts = nullptr;                  // 16 x uint32 pinned host mirror of the round state
     uint64_t capacity = 0;                         // n_local the buffers were sized for
     hipStream_t side_stream = nullptr;             // a round's shadow-ray launch runs here, next to the closest-hit launch
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 size_t wavefront_state_bytes(uint64_t n_local);
 size_t wavefront_queue_bytes(uint64_t n_local);
-// Runs a whole frame; synchronises `stream` once per round (to size the next round's launches).
+size_t wavefront_counter_bytes();
+// Runs a whole frame; the rounds are enqueued without host round trips (device-side round state), `stream` is
+// synchronised once per batch of rounds - once per frame in the normal case.
 hipError_t launch_wavefront(const RenderParams& p, int kernel, bool fused, bool count, WavefrontBuffers& buf,
                             hipStream_t stream, uint32_t* rounds_out);
 

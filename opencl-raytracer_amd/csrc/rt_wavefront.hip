@@ -46,14 +46,29 @@ constexpr uint32_t PH_FLAG_REFLECTION_SENT = 0x100u;
 // ... and it has not been traced yet (set for exactly the round that follows its emission; wf_finish needs to know)
 constexpr uint32_t PH_FLAG_REFLECTION_PENDING = 0x200u;
 
+// Round state, in device memory (WavefrontBuffers::counts). The host enqueues a frame's rounds WITHOUT waiting for the
+// queue lengths: every kernel of a round reads them from here (resolve_round) and a one-block kernel between rounds
+// (wf_advance) turns the queues a round has filled into the input of the next one. Launch grids are sized for the
+// most a queue can hold; surplus workgroups exit on their first comparison.
+enum : uint32_t {
+    RS_NEXT_CLOSEST = 0, RS_NEXT_ANY = 1,   // append counters of the queues being filled (block_push)
+    RS_SLICE_A = 2, RS_SLICE_B = 3,         // survivors of a shadow slice (brute-force path), ping-pong
+    RS_N_CLOSEST = 4, RS_N_ANY = 5,         // lengths of the queues the current round consumes
+    RS_CUR = 6,                             // which queue pair that is
+    RS_FINISH = 7,                          // 0: rounds go on, 1: the rest belongs to wf_finish, 2: nothing left
+    RS_ROUNDS = 8,                          // rounds that had work (statistics)
+    RS_WORDS = 16
+};
+
 struct WfParams {
     RenderParams rp;
     float* st;            // F_COUNT x n_local floats
-    uint32_t* q_closest;  // queue of pixel ids waiting for a closest-hit trace (this round)
-    uint32_t* q_any;      // ... for an any-hit trace
-    uint32_t* q_prev_closest;
+    uint32_t* qs[2][2];   // two queue pairs {closest-hit, any-hit} of pixel ids; a round consumes one pair and fills the other
+    uint32_t* q_closest;  // -- resolved per kernel from the round state (resolve_round): the queues being filled ...
+    uint32_t* q_any;
+    uint32_t* q_prev_closest;  // ... and the queues being consumed, with their lengths
     uint32_t* q_prev_any;
-    uint32_t* counts;     // [0] closest next, [1] any next, [2] shadow-slice survivors (device counters)
+    uint32_t* counts;     // the round state (RS_*) followed by the run-ticket counters of the grid walk
     const HotPair* shadow_pairs;  // pair stream sorted by decreasing size, for order-free shadow tests
     GridDesc grid;                // conservative uniform grid (enabled = 0: brute force)
     ScreenTiles tiles;            // screen-tile object lists for pinhole primary rays
@@ -62,6 +77,20 @@ struct WfParams {
     uint32_t first_round;  // the closest-hit rays of this round are the primary rays (never stored: closest_ray())
     uint32_t count_rays;  // instrumentation on
 };
+
+// Kernel prologue: the round's queues and their lengths, read from device memory (wave-uniform scalar loads; the
+// values were written by wf_advance, an earlier kernel of the same stream). False: the frame is past its rounds.
+__device__ __forceinline__ bool resolve_round(WfParams& w) {
+    const uint32_t* rs = w.counts;
+    const bool odd = (rs[RS_CUR] & 1u) != 0u;  // (selects, not a run-time index: the struct must stay in scalar registers)
+    w.q_prev_closest = odd ? w.qs[1][0] : w.qs[0][0];
+    w.q_prev_any = odd ? w.qs[1][1] : w.qs[0][1];
+    w.q_closest = odd ? w.qs[0][0] : w.qs[1][0];
+    w.q_any = odd ? w.qs[0][1] : w.qs[1][1];
+    w.n_prev_closest = rs[RS_N_CLOSEST];
+    w.n_prev_any = rs[RS_N_ANY];
+    return rs[RS_FINISH] == 0u;
+}
 
 // Work-item -> pixel of this rank's frame part. Pinhole frames are walked in 8x8-pixel tiles (work-items 64k ..
 // 64k+63 = one tile), so that the 64 rays a wave traces together, and the rays in flight on the chip, are
@@ -157,7 +186,9 @@ __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
 __device__ __forceinline__ bool begin_pixel(const WfParams& w, uint64_t i);
 
 // ---- wf_begin: primary rays --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kResumeThreads) void wf_begin(const WfParams w) {
+__global__ __launch_bounds__(kResumeThreads) void wf_begin(const WfParams wk) {
+    WfParams w = wk;
+    (void)resolve_round(w);
     const RenderParams& p = w.rp;
     const uint64_t i = (uint64_t)blockIdx.x * kResumeThreads + threadIdx.x;
     bool want = false;
@@ -214,9 +245,11 @@ __device__ __forceinline__ bool begin_pixel(const WfParams& w, uint64_t i) {
 
 // ---- lean traversal kernels ----------------------------------------------------------------------------------------
 template <bool FUSED, bool DW0>
-__global__ __launch_bounds__(256) void wf_trace_closest(const WfParams w, uint32_t n_queue) {
+__global__ __launch_bounds__(256) void wf_trace_closest(const WfParams wk) {
+    WfParams w = wk;
+    if (!resolve_round(w)) return;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n_queue) return;
+    if (t >= w.n_prev_closest) return;
     const uint64_t i = w.q_prev_closest[t];
     const Ray ray = closest_ray(w, i, w.first_round != 0u);
     float T = kMaxFloat;
@@ -249,9 +282,11 @@ __device__ __forceinline__ void tile_candidate(const RT_CONST HotObjectC* o, int
 // walks that tile's object list with wave-uniform scalar loads (plus the always-list). Waves that straddle tiles
 // (ragged ends) fall back to the per-lane grid walk. Order-free tie rules, so the result is the same either way.
 template <bool FUSED>
-__global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams w, uint32_t n_queue) {
+__global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams wk) {
+    WfParams w = wk;
+    if (!resolve_round(w)) return;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n_queue) return;
+    if (t >= w.n_prev_closest) return;
     const RenderParams& p = w.rp;
     const uint64_t i = w.q_prev_closest[t];
     const uint64_t g = global_ray_of(p, i);
@@ -269,8 +304,12 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams w, 
             const int k = (int)w.grid.always[a];
             tile_candidate<FUSED>(hot + k, k, ray, T, idx, cur_sphere);
         }
+        for (uint32_t a = 0; a < w.tiles.n_global; ++a) {  // objects that project onto the whole screen
+            const int k = (int)w.tiles.entries[w.tiles.global_begin + a];
+            tile_candidate<FUSED>(hot + k, k, ray, T, idx, cur_sphere);
+        }
         const uint32_t e0 = w.tiles.tile_start[first], e1 = w.tiles.tile_start[first + 1];
-        tested = w.grid.n_always + (e1 - e0);
+        tested = w.grid.n_always + w.tiles.n_global + (e1 - e0);
         for (uint32_t e = e0; e < e1; ++e) {
             const int k = (int)w.tiles.entries[e];
             tile_candidate<FUSED>(hot + k, k, ray, T, idx, cur_sphere);
@@ -297,6 +336,13 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams w, 
 #define RT_SEGMENT 128  // queue entries per run (64: 33.8 ms per cfg4 frame, 128: 32.2)
 #endif
 constexpr uint32_t kSegment = RT_SEGMENT;
+#ifndef RT_TICKET_REGIONS
+#define RT_TICKET_REGIONS 1  // ticket counters per launch; 8 = one region of the queue per XCD (measured: 24.0 vs 24.0-24.3 ms per cfg4 frame - no gain, the walk is instruction-bound)
+#endif
+constexpr uint32_t kTicketRegions = RT_TICKET_REGIONS;
+constexpr uint32_t kTicketStride = 16;   // one counter per 64-byte line
+constexpr uint32_t kTicketWords = 16u * kTicketStride;  // room for up to 16 regions per launch
+constexpr uint32_t kTicketBase = 16;     // counts[16 ..]: closest-hit launch, counts[16 + kTicketWords ..]: shadow launch
 
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 16  // new rays are handed out once this many lanes are idle (setting a ray up is ~150 instructions)
@@ -330,14 +376,32 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
     const uint32_t n_runs = (n_queue + kSegment - 1u) / kSegment;
     const bool dynamic = n_runs > n_waves;
     uint32_t next = 0, seg_end = 0;  // wave-uniform cursor into the current run
+    // Dynamic hand-out, XCD-affine: the queue is cut into kTicketRegions contiguous regions with one ticket counter
+    // each; a wave draws from the region of the XCD it runs on (HW_REG_XCC_ID - placement is only a speed matter)
+    // and moves on to the next region when its own is used up. Each XCD has its own L2: this way the rays in flight
+    // on one XCD are neighbours in the queue (= in the image), instead of a 1/8 sample of the whole chip's
+    // neighbourhood, so an XCD's L2 holds an eighth of the cells / spheres / matrices the chip is working on.
+    uint32_t region = 0, regions_tried = 0;
+    if (kTicketRegions > 1u) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        region = (xcc & 0xfu) % kTicketRegions;
+    }
     auto grab = [&]() -> bool {
-        uint32_t r = 0;
-        if (lane == 0u) r = atomicAdd(run_ctr, 1u);
-        r = __builtin_amdgcn_readfirstlane(r);
-        if (r >= n_runs) return false;
-        next = r * kSegment;
-        seg_end = (n_queue - next < kSegment) ? n_queue : next + kSegment;
-        return true;
+        for (;;) {
+            const uint32_t lo = (uint32_t)(((uint64_t)n_runs * region) / kTicketRegions);
+            const uint32_t hi = (uint32_t)(((uint64_t)n_runs * (region + 1u)) / kTicketRegions);
+            uint32_t r = 0;
+            if (lane == 0u) r = atomicAdd(run_ctr + region * kTicketStride, 1u);
+            r = __builtin_amdgcn_readfirstlane(r) + lo;
+            if (r < hi) {
+                next = r * kSegment;
+                seg_end = (n_queue - next < kSegment) ? n_queue : next + kSegment;
+                return true;
+            }
+            if (++regions_tried >= kTicketRegions) return false;
+            region = (region + 1u == kTicketRegions) ? 0u : region + 1u;
+        }
     };
     bool more = dynamic;  // may another run be drawn?
     if (dynamic) {
@@ -382,7 +446,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                     bool sphere;
                     const bool cand = lane_candidate<FUSED, true, TRI>(hot + k, ray, t, sphere);
                     if (STATS) ++tested;
-                    if (ANY) done = cand && t < 1.f;
+                    if (ANY) done = cand && !(t >= 1.f);
                     else if (cand) closest_take(t, k, sphere, T, idx, cur_sphere);
                 }
                 dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
@@ -391,7 +455,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 if (!done) w0 = walk_begin(g, ray, ANY ? 1.0f + slack : 3.0e38f);
                 wk = lean_walk(g, w0);
                 if (done || !w0.alive) {  // occluded by an always-object, or the ray misses the grid box
-                    if (ANY) U(w, F_RES_ANY, pix) = done ? 0u : 1u;
+                    if (ANY) U(w, F_RES_ANY, pix) = (done || nan_shadow_blocked(w.rp.scene, ray)) ? 0u : 1u;
                     else { F(w, F_RES_T, pix) = T; U(w, F_RES_I, pix) = (uint32_t)idx; }
                 } else {
                     st = 1;
@@ -455,7 +519,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                     if (STATS) ++tested;
                     pend = false;
                     if (ANY) {
-                        if (cand && t < 1.f) { U(w, F_RES_ANY, pix) = 0u; st = 0; }
+                        if (cand && !(t >= 1.f)) { U(w, F_RES_ANY, pix) = 0u; st = 0; }
                     } else if (cand) {
                         closest_take(t, pend_k, sphere, T, idx, cur_sphere);
                     }
@@ -485,8 +549,13 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
 #define RT_WAVES_PER_EU_TRI 6  // the variants that know triangles would like ~90 VGPRs; 5 waves without spills measured slower (97.6 vs 93 ms, cfg5)
 #endif
 template <bool FUSED, bool ANY, bool STATS, bool TRI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRI ? RT_WAVES_PER_EU_TRI : RT_WAVES_PER_EU))) void wf_trace_grid_persistent(const WfParams w, const uint32_t* __restrict__ queue, uint32_t n_queue,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRI ? RT_WAVES_PER_EU_TRI : RT_WAVES_PER_EU))) void wf_trace_grid_persistent(const WfParams wk,
                                                                  uint32_t* __restrict__ run_ctr) {
+    WfParams w = wk;
+    if (!resolve_round(w)) return;
+    const uint32_t* queue = ANY ? w.q_prev_any : w.q_prev_closest;
+    const uint32_t n_queue = ANY ? w.n_prev_any : w.n_prev_closest;
+    if (n_queue == 0u) return;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * 256u) >> 6;
     unsigned long long tested = 0;
@@ -496,9 +565,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRI ? RT_WA
 
 // Literal shadow test: the reference's full closest hit, then its `time >= 1 || time < 0` (:229).
 template <bool FUSED>
-__global__ __launch_bounds__(256) void wf_trace_any_literal(const WfParams w, uint32_t n_queue) {
+__global__ __launch_bounds__(256) void wf_trace_any_literal(const WfParams wk) {
+    WfParams w = wk;
+    if (!resolve_round(w)) return;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= n_queue) return;
+    if (t >= w.n_prev_any) return;
     const uint64_t i = w.q_prev_any[t];
     const Ray ray = load_ray(w, i, kSlotShadow);
     float T = kMaxFloat;
@@ -517,14 +588,24 @@ __global__ __launch_bounds__(256) void wf_trace_any_literal(const WfParams w, ui
 // its first occluder no matter what the other 63 lanes of its wave are doing - the wave-wide early exit of a
 // single long loop almost never fires, because one lit lane keeps the whole wave going.
 template <bool FUSED>
-__global__ __launch_bounds__(256) void wf_trace_any_slice(const WfParams w, const uint32_t* __restrict__ q_in, uint32_t n_queue,
+__global__ __launch_bounds__(256) void wf_trace_any_slice(const WfParams wk, const uint32_t* __restrict__ q_in, const uint32_t* __restrict__ n_in,
                                                           uint32_t pair_lo, uint32_t pair_hi, uint32_t* __restrict__ q_out,
                                                           uint32_t* __restrict__ out_count, uint32_t first_slice) {
+    WfParams w = wk;
+    if (!resolve_round(w)) return;
+    // the first slice reads the round's shadow queue, later ones the survivors of the slice before
+    const uint32_t n_queue = first_slice ? w.n_prev_any : *n_in;
+    if (first_slice) q_in = w.q_prev_any;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= n_queue) return;
     const uint32_t i = q_in[t];
     const Ray ray = load_ray(w, i, kSlotShadow);
     uint32_t visited = 0;
+    const int nan_kind = nan_ray_outcome(ray, w.rp.scene.nan_winner, w.rp.scene.nan_winner_sphere);
+    if (__ballot(nan_kind != kNanRayNone) != 0ull && nan_kind != kNanRayNone) {  // the size-sorted stream is order-free, a NaN ray's outcome is not
+        U(w, F_RES_ANY, i) = (nan_kind == kNanRayTimeNaN) ? 0u : 1u;
+        return;
+    }
     const bool occluded = any_hit_before_one<FUSED>(w.shadow_pairs + pair_lo, pair_hi - pair_lo, ray, &visited);
     if (w.count_rays) {  // `visited` is wave-uniform: every lane rides along until the wave leaves
         const unsigned long long lanes = (unsigned long long)__popcll(__ballot(true));
@@ -548,9 +629,12 @@ __global__ __launch_bounds__(256) void wf_trace_any_slice(const WfParams w, cons
 __device__ __forceinline__ void closest_result(const WfParams& w, uint64_t i, bool primary, float& T, int& idx) {
     T = F(w, F_RES_T, i);
     idx = (int)U(w, F_RES_I, i);
-    if (T == kMaxFloat && w.grid.enabled && !w.rp.scene.literal && w.grid.nan_winner >= 0) {
+    if (T == kMaxFloat && w.grid.enabled && !w.rp.scene.literal && w.rp.scene.nan_winner >= 0) {
         const Ray ray = closest_ray(w, i, primary);
-        if (ray_has_nan(ray)) { T = __builtin_nanf(""); idx = w.grid.nan_winner; }
+        if (nan_ray_outcome(ray, w.rp.scene.nan_winner, w.rp.scene.nan_winner_sphere) == kNanRayTimeNaN) {
+            T = __builtin_nanf("");
+            idx = w.rp.scene.nan_winner;
+        }
     }
 }
 
@@ -851,7 +935,10 @@ __device__ __forceinline__ void add_ray_counters(const WfParams& w, const Ctx& c
 #define RT_RESUME_WAVES_PER_EU 4
 #endif
 template <int KERNEL, bool FUSED>
-__global__ __launch_bounds__(kResumeThreads) __attribute__((amdgpu_waves_per_eu(RT_RESUME_WAVES_PER_EU))) void wf_resume(const WfParams w) {
+__global__ __launch_bounds__(kResumeThreads) __attribute__((amdgpu_waves_per_eu(RT_RESUME_WAVES_PER_EU))) void wf_resume(const WfParams wk) {
+    WfParams w = wk;
+    if (!resolve_round(w)) return;
+    if (blockIdx.x * kResumeThreads >= w.n_prev_closest + w.n_prev_any) return;  // the grid is sized for the most the queues can hold
     const uint32_t t = blockIdx.x * kResumeThreads + threadIdx.x;
     const uint32_t total = w.n_prev_closest + w.n_prev_any;
     Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u};
@@ -869,7 +956,10 @@ __global__ __launch_bounds__(kResumeThreads) __attribute__((amdgpu_waves_per_eu(
 // machine to the end in one thread, tracing its rays itself through the grid (closest_hit_grid / any_hit_grid: same
 // cells, same exact tests, same results as the wave-level walk).
 template <int KERNEL, bool FUSED>
-__global__ __launch_bounds__(256) void wf_finish(const WfParams w) {
+__global__ __launch_bounds__(256) void wf_finish(const WfParams wk) {
+    WfParams w = wk;
+    (void)resolve_round(w);
+    if (w.counts[RS_FINISH] != 1u) return;  // only once wf_advance has handed the rest of the frame over
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t total = w.n_prev_closest + w.n_prev_any;
     Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u};
@@ -883,7 +973,7 @@ __global__ __launch_bounds__(256) void wf_finish(const WfParams w) {
             for (;;) {
                 if (do_any) {
                     const Ray ray = load_ray(w, c.i, kSlotShadow);
-                    U(w, F_RES_ANY, c.i) = any_hit_grid<FUSED>(w.grid, w.rp.scene.hot, ray, tested) ? 0u : 1u;
+                    U(w, F_RES_ANY, c.i) = any_hit_grid<FUSED>(w.grid, w.rp.scene, ray, tested) ? 0u : 1u;
                 }
                 if (do_closest) {
                     const Ray ray = load_ray(w, c.i, kSlotClosest);
@@ -911,6 +1001,24 @@ __global__ __launch_bounds__(256) void wf_finish(const WfParams w) {
 constexpr uint32_t kMinSlicePairs = 2048;
 constexpr uint32_t kMaxSlices = 16;
 
+// Between two rounds (one workgroup): the queues the round has filled become the next round's input, their append
+// counters and the grid walk's run tickets start from zero again, and the frame's tail is handed to wf_finish once
+// few enough pixels are alive.
+__global__ __launch_bounds__(256) void wf_advance(uint32_t* __restrict__ rs, uint32_t finish_threshold, uint32_t allow_finish) {
+    for (uint32_t k = threadIdx.x; k < 2u * kTicketWords; k += 256u) rs[kTicketBase + k] = 0u;
+    if (threadIdx.x != 0u) return;
+    if (rs[RS_FINISH] != 0u) return;  // the frame is already past its rounds: leave the hand-over as it is
+    const uint32_t nc = rs[RS_NEXT_CLOSEST], na = rs[RS_NEXT_ANY];
+    rs[RS_N_CLOSEST] = nc;
+    rs[RS_N_ANY] = na;
+    rs[RS_NEXT_CLOSEST] = 0u;
+    rs[RS_NEXT_ANY] = 0u;
+    rs[RS_CUR] ^= 1u;
+    if (nc + na == 0u) rs[RS_FINISH] = 2u;
+    else if (allow_finish && nc + na <= finish_threshold) rs[RS_FINISH] = 1u;
+    else rs[RS_ROUNDS] += 1u;
+}
+
 // ---- host driver -----------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255u) / 256u)); }
 // one wave per kSegment queue entries, four waves per workgroup
@@ -920,135 +1028,151 @@ static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255u) / 25
 static inline dim3 persistent_grid(uint64_t n) {
     uint64_t waves = (n + kSegment - 1) / kSegment;
     if (waves > (uint64_t)RT_MAX_WAVES) waves = RT_MAX_WAVES;
+    if (waves == 0) waves = 1;
     return dim3((uint32_t)((waves + 3u) / 4u));
 }
 
 size_t wavefront_state_bytes(uint64_t n_local) { return (size_t)F_COUNT * sizeof(float) * (size_t)n_local; }
 size_t wavefront_queue_bytes(uint64_t n_local) { return sizeof(uint32_t) * (size_t)n_local; }
+size_t wavefront_counter_bytes() { return sizeof(uint32_t) * (size_t)(kTicketBase + 2u * kTicketWords); }
 
-// one launch of the persistent grid walk (the template arguments pick the compiled variant)
+// one launch of the persistent grid walk (the template arguments pick the compiled variant); `n_max` = the most the
+// queue can hold, the kernel reads its real length from the round state
 template <bool FUSED, bool ANY>
-static void launch_persistent(const WfParams& w, const uint32_t* queue, uint32_t n, uint32_t* ticket, hipStream_t s) {
-    const dim3 grid = persistent_grid(n), block(256);
+static void launch_persistent(const WfParams& w, uint64_t n_max, uint32_t* ticket, hipStream_t s) {
+    const dim3 grid = persistent_grid(n_max), block(256);
     const bool tri = w.grid.has_triangles != 0u;
     if (w.count_rays) {
-        if (tri) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, true, true>), grid, block, 0, s, w, queue, n, ticket);
-        else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, true, false>), grid, block, 0, s, w, queue, n, ticket);
+        if (tri) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, true, true>), grid, block, 0, s, w, ticket);
+        else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, true, false>), grid, block, 0, s, w, ticket);
     } else {
-        if (tri) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, false, true>), grid, block, 0, s, w, queue, n, ticket);
-        else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, false, false>), grid, block, 0, s, w, queue, n, ticket);
+        if (tri) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, false, true>), grid, block, 0, s, w, ticket);
+        else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, false, false>), grid, block, 0, s, w, ticket);
     }
 }
 
+// A frame = wf_begin, then rounds of {trace closest || trace any} -> wf_resume -> wf_advance, then wf_finish. The
+// rounds are enqueued in batches without looking at the queue lengths (device-side round state); the host reads the
+// state back once per batch - once per frame when the first batch (as many rounds as the kernel's control flow
+// needs at least) gets the frame down to wf_finish's share, which is the normal case.
 template <int KERNEL, bool FUSED>
 static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t stream, uint32_t* rounds_out) {
     hipError_t e;
     const uint64_t n = w.rp.n_local;
-    uint32_t* q[2][2] = {{buf.q_closest[0], buf.q_any[0]}, {buf.q_closest[1], buf.q_any[1]}};
-    int cur = 0;
-    if ((e = hipMemsetAsync(buf.counts, 0, 3 * sizeof(uint32_t), stream)) != hipSuccess) return e;
     w.st = buf.state;
     w.counts = buf.counts;
     w.shadow_pairs = buf.shadow_pairs;
     w.grid = buf.grid;
     w.tiles = buf.tiles;
-    w.q_closest = q[cur][0];
-    w.q_any = q[cur][1];
-    hipLaunchKernelGGL(wf_begin, dim3((uint32_t)((n + kResumeThreads - 1) / kResumeThreads)), dim3(kResumeThreads), 0, stream, w);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    uint32_t rounds = 0;
-    bool first = true;
+    for (int a = 0; a < 2; ++a) { w.qs[a][0] = buf.q_closest[a]; w.qs[a][1] = buf.q_any[a]; }
+    uint32_t* rs = buf.counts;
+    if ((e = hipMemsetAsync(rs, 0, wavefront_counter_bytes(), stream)) != hipSuccess) return e;
     // at or below this many live pixels the frame is finished by wf_finish instead of further rounds
     uint64_t finish_threshold = std::max<uint64_t>(2048, n / 128);
     if (const char* env = std::getenv("RT_WF_FINISH_THRESHOLD")) finish_threshold = (uint64_t)std::atoll(env);
-    for (;;) {
-        // how many rays did the last stage queue?  (one small D2H + sync per round; a round is >= N x 35 VALU
-        // instructions per ray, so this is noise for the scene sizes this path is used for)
-        if ((e = hipMemcpyAsync(buf.h_counts, buf.counts, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-        const uint32_t nc = buf.h_counts[0], na = buf.h_counts[1];
-        if (nc == 0 && na == 0) break;
-        ++rounds;
-        w.q_prev_closest = q[cur][0];
-        w.q_prev_any = q[cur][1];
-        w.n_prev_closest = nc;
-        w.n_prev_any = na;
+    if (finish_threshold > 0xffffffffull) finish_threshold = 0xffffffffull;
+    const bool use_grid = w.grid.enabled && !w.rp.scene.literal;
+    hipLaunchKernelGGL(wf_begin, dim3((uint32_t)((n + kResumeThreads - 1) / kResumeThreads)), dim3(kResumeThreads), 0, stream, w);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    hipLaunchKernelGGL(wf_advance, dim3(1), dim3(256), 0, stream, rs, (uint32_t)finish_threshold, 0u);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+
+    static const bool one_stream = std::getenv("RT_WF_ONE_STREAM") != nullptr;  // measurement knob
+    auto enqueue_round = [&](bool first, uint64_t nc_max, uint64_t na_max) -> hipError_t {
+        hipError_t e2;
         w.first_round = first ? 1u : 0u;
-        const bool use_grid = w.grid.enabled && !w.rp.scene.literal;
-        if (use_grid && !first && (uint64_t)nc + na <= finish_threshold) {
-            hipLaunchKernelGGL((wf_finish<KERNEL, FUSED>), grid_for((uint64_t)nc + na), dim3(256), 0, stream, w);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-            break;
-        }
-        if (use_grid && (e = hipMemsetAsync(buf.counts + 4, 0, 2 * sizeof(uint32_t), stream)) != hipSuccess) return e;
         // The two launches of a round are independent (different rays, different result words): through the grid they
         // run side by side on two streams, so that each fills the other's tail and a small light-scan queue hides
         // behind a big reflection queue.
-        static const bool one_stream = std::getenv("RT_WF_ONE_STREAM") != nullptr;  // measurement knob
-        const bool side_by_side = use_grid && nc && na && buf.side_stream && !one_stream;
+        const bool side_by_side = use_grid && nc_max && na_max && buf.side_stream && !one_stream;
         hipStream_t any_stream = stream;
         if (side_by_side) {
             any_stream = buf.side_stream;
-            if ((e = hipEventRecord(buf.ev_fork, stream)) != hipSuccess) return e;
-            if ((e = hipStreamWaitEvent(any_stream, buf.ev_fork, 0)) != hipSuccess) return e;
-            launch_persistent<FUSED, true>(w, w.q_prev_any, na, buf.counts + 5, any_stream);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
-            if ((e = hipEventRecord(buf.ev_join, any_stream)) != hipSuccess) return e;
+            if ((e2 = hipEventRecord(buf.ev_fork, stream)) != hipSuccess) return e2;
+            if ((e2 = hipStreamWaitEvent(any_stream, buf.ev_fork, 0)) != hipSuccess) return e2;
+            launch_persistent<FUSED, true>(w, na_max, rs + kTicketBase + kTicketWords, any_stream);
+            if ((e2 = hipGetLastError()) != hipSuccess) return e2;
+            if ((e2 = hipEventRecord(buf.ev_join, any_stream)) != hipSuccess) return e2;
         }
-        if (nc) {
+        if (nc_max) {
             if (use_grid && first && w.tiles.enabled && w.rp.pinhole) {
-                hipLaunchKernelGGL((wf_trace_primary_tiles<FUSED>), grid_for(nc), dim3(256), 0, stream, w, nc);
+                hipLaunchKernelGGL((wf_trace_primary_tiles<FUSED>), grid_for(nc_max), dim3(256), 0, stream, w);
             } else if (use_grid) {
-                launch_persistent<FUSED, false>(w, w.q_prev_closest, nc, buf.counts + 4, stream);  // (a grid implies direction.w = 0)
+                launch_persistent<FUSED, false>(w, nc_max, rs + kTicketBase, stream);  // (a grid implies direction.w = 0)
             } else {
-                if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest<FUSED, false>), grid_for(nc), dim3(256), 0, stream, w, nc);
-                else hipLaunchKernelGGL((wf_trace_closest<FUSED, true>), grid_for(nc), dim3(256), 0, stream, w, nc);
+                if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest<FUSED, false>), grid_for(nc_max), dim3(256), 0, stream, w);
+                else hipLaunchKernelGGL((wf_trace_closest<FUSED, true>), grid_for(nc_max), dim3(256), 0, stream, w);
             }
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if ((e2 = hipGetLastError()) != hipSuccess) return e2;
         }
         if (side_by_side) {
-            if ((e = hipStreamWaitEvent(stream, buf.ev_join, 0)) != hipSuccess) return e;
-        } else if (na) {
+            if ((e2 = hipStreamWaitEvent(stream, buf.ev_join, 0)) != hipSuccess) return e2;
+        } else if (na_max) {
             if (w.rp.scene.literal) {
-                hipLaunchKernelGGL((wf_trace_any_literal<FUSED>), grid_for(na), dim3(256), 0, stream, w, na);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
+                hipLaunchKernelGGL((wf_trace_any_literal<FUSED>), grid_for(na_max), dim3(256), 0, stream, w);
+                if ((e2 = hipGetLastError()) != hipSuccess) return e2;
             } else if (use_grid) {
-                launch_persistent<FUSED, true>(w, w.q_prev_any, na, buf.counts + 5, stream);
-                if ((e = hipGetLastError()) != hipSuccess) return e;
+                launch_persistent<FUSED, true>(w, na_max, rs + kTicketBase + kTicketWords, stream);
+                if ((e2 = hipGetLastError()) != hipSuccess) return e2;
             } else {
-                // slices of >= kMinSlicePairs pairs (amortises each launch's pipeline fill), at most kMaxSlices
+                // slices of >= kMinSlicePairs pairs (amortises each launch's pipeline fill), at most kMaxSlices; the
+                // survivors of a slice are the next one's queue (lengths stay on the device)
                 const uint32_t n_pairs = w.rp.scene.n_pairs;
                 uint32_t n_slices = n_pairs / kMinSlicePairs;
                 n_slices = n_slices < 1u ? 1u : (n_slices > kMaxSlices ? kMaxSlices : n_slices);
-                const uint32_t* q_in = w.q_prev_any;
-                uint32_t n_in = na;
-                for (uint32_t sl = 0; sl < n_slices && n_in; ++sl) {
+                for (uint32_t sl = 0; sl < n_slices; ++sl) {
                     const uint32_t lo = (uint32_t)((uint64_t)n_pairs * sl / n_slices);
                     const uint32_t hi = (uint32_t)((uint64_t)n_pairs * (sl + 1) / n_slices);
                     const bool last = (sl + 1 == n_slices);
                     uint32_t* q_out = last ? nullptr : buf.q_slice[sl & 1u];
-                    if (!last && (e = hipMemsetAsync(buf.counts + 2, 0, sizeof(uint32_t), stream)) != hipSuccess) return e;
-                    hipLaunchKernelGGL((wf_trace_any_slice<FUSED>), grid_for(n_in), dim3(256), 0, stream, w, q_in, n_in, lo, hi,
-                                       q_out, buf.counts + 2, sl == 0 ? 1u : 0u);
-                    if ((e = hipGetLastError()) != hipSuccess) return e;
-                    if (last) break;
-                    if ((e = hipMemcpyAsync(buf.h_counts + 2, buf.counts + 2, sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
-                    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-                    n_in = buf.h_counts[2];
-                    q_in = q_out;
+                    uint32_t* n_out = rs + (sl & 1u ? RS_SLICE_B : RS_SLICE_A);
+                    const uint32_t* q_in = sl ? buf.q_slice[(sl - 1u) & 1u] : nullptr;
+                    const uint32_t* n_in = rs + ((sl - 1u) & 1u ? RS_SLICE_B : RS_SLICE_A);
+                    if (!last && (e2 = hipMemsetAsync(n_out, 0, sizeof(uint32_t), stream)) != hipSuccess) return e2;
+                    hipLaunchKernelGGL((wf_trace_any_slice<FUSED>), grid_for(na_max), dim3(256), 0, stream, w, q_in, n_in, lo, hi,
+                                       q_out, n_out, sl == 0 ? 1u : 0u);
+                    if ((e2 = hipGetLastError()) != hipSuccess) return e2;
                 }
             }
         }
-        first = false;
-        cur ^= 1;
-        w.q_closest = q[cur][0];
-        w.q_any = q[cur][1];
-        if ((e = hipMemsetAsync(buf.counts, 0, 2 * sizeof(uint32_t), stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL((wf_resume<KERNEL, FUSED>), dim3((uint32_t)(((uint64_t)nc + na + kResumeThreads - 1) / kResumeThreads)),
+        const uint64_t total_max = nc_max + na_max;
+        hipLaunchKernelGGL((wf_resume<KERNEL, FUSED>), dim3((uint32_t)((total_max + kResumeThreads - 1) / kResumeThreads)),
                            dim3(kResumeThreads), 0, stream, w);
-        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e2 = hipGetLastError()) != hipSuccess) return e2;
+        hipLaunchKernelGGL(wf_advance, dim3(1), dim3(256), 0, stream, rs, (uint32_t)finish_threshold, use_grid ? 1u : 0u);
+        return hipGetLastError();
+    };
+
+    // rounds the kernel's control flow needs at least (then the host looks): hittest 1; shade one per light; shade_and_reflect
+    // one per bounce + 2 (the reflection ray leaves with the hit's first shadow ray), more in literal mode
+    uint32_t batch = 1;
+    if (KERNEL == 1) batch = w.rp.scene.n_lights + 1u;
+    else if (KERNEL == 2) batch = w.rp.scene.literal ? 8u : w.rp.max_bounces + 2u;
+    if (batch > 12u) batch = 12u;
+    if (const char* env = std::getenv("RT_WF_BATCH")) batch = (uint32_t)std::max(1, std::atoi(env));
+    bool first = true;
+    uint64_t nc_max = n, na_max = 0;  // the first round traces the primary rays only
+    for (;;) {
+        for (uint32_t r = 0; r < batch; ++r) {
+            if ((e = enqueue_round(first, nc_max, na_max)) != hipSuccess) return e;
+            if (first) { first = false; nc_max = (KERNEL == 0) ? 0 : n; na_max = (KERNEL == 0) ? 0 : n; }
+            if (nc_max + na_max == 0) break;
+        }
+        if (use_grid) {
+            hipLaunchKernelGGL((wf_finish<KERNEL, FUSED>), grid_for(finish_threshold ? finish_threshold : 1), dim3(256), 0, stream, w);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if ((e = hipMemcpyAsync(buf.h_counts, rs, RS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        if (buf.h_counts[RS_FINISH] != 0u) break;  // 2: the queues ran empty; 1: wf_finish (enqueued above) took the rest
+        if (nc_max + na_max == 0) break;
+        // still going (long light scans, deep bounce chains): what is alive bounds every later queue
+        const uint64_t alive = (uint64_t)buf.h_counts[RS_N_CLOSEST] + buf.h_counts[RS_N_ANY];
+        nc_max = std::min<uint64_t>(n, alive);
+        na_max = std::min<uint64_t>(n, alive);
+        batch = 8;
     }
-    if (rounds_out) *rounds_out = rounds;
+    if (rounds_out) *rounds_out = buf.h_counts[RS_ROUNDS];
     return hipSuccess;
 }
 

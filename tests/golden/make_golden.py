@@ -206,5 +206,67 @@ def main():
     save("no_objects_shade", "shade", R.objects_array([]), R.lights_array([light((1, 1, 1, 1))]), 0, cam=(16, 16, 60.0))
 
 
+def round2():
+    """Fixtures added in round 2 (same generator, same reference kernels): the reference's SHIPPED bounce depth
+    (MAX_BOUNCES = 30, OpenCL-Raytracer.cpp:75) on its own sample scenes and on the facing-mirror scene, NaN shadow
+    rays, and degenerate instances whose NaN hit times make the loop's result depend on the object order."""
+    # the reference's shipped workload is 2560x1440, fov 60, MAX_BOUNCES 30 (OpenCL-Raytracer.cpp:31-33,75): same
+    # aspect ratio and depth at 1/16 of the resolution
+    for scene in ("roundedCube", "simpleScene"):
+        objs, lights = scene_loader.load_scene(str(SCENES / f"{scene}.txt"))
+        save(f"shipped_{scene}_160x90_D30", "shade_and_reflect", objs, lights, 30, cam=(160, 90, 60.0))
+    # unsigned post-decrement exhaustion (Q8, .cl:268,281) at odd / even / shipped depths
+    for a in (0.5, 0.2):
+        facing = R.objects_array([
+            obj(R.SPHERE, mat((.3, .1, .1), (.5, .5, .2), (.8, .8, .8), absorption=a, shininess=10.0), (-2.2, 0, -10), scale=(2, 2, 2)),
+            obj(R.SPHERE, mat((.1, .3, .1), (.2, .5, .5), (.8, .8, .8), absorption=a, shininess=10.0), (2.2, 0, -10), scale=(2, 2, 2)),
+            obj(R.BOX, mat((.1, .1, .3), (.4, .4, .6), (.5, .5, .5), absorption=a, shininess=3.0), (0, -3.5, -10), scale=(12, 1, 8)),
+        ])
+        fl = R.lights_array([light((5, 12, 2, 1))])
+        for D in (7, 30):
+            save(f"bounce_a{a}_D{D}", "shade_and_reflect", facing, fl, D, cam=(48, 32, 60.0))
+    # a mirror corridor: two big facing boxes with absorption .05 - paths really use all 30 bounces
+    corridor = R.objects_array([
+        obj(R.BOX, mat((.2, .2, .2), (.4, .4, .4), (.6, .6, .6), absorption=.05, shininess=20.0), (-3, 0, -12), scale=(1, 8, 10)),
+        obj(R.BOX, mat((.2, .2, .2), (.4, .4, .4), (.6, .6, .6), absorption=.05, shininess=20.0), (3, 0, -12), scale=(1, 8, 10)),
+        obj(R.SPHERE, mat((.6, .1, .1), (.6, .3, .3), (.9, .9, .9), absorption=.6, shininess=8.0), (0, 0, -12), scale=(.8, .8, .8)),
+    ])
+    save("corridor_D30", "shade_and_reflect", corridor, R.lights_array([light((0, 6, -6, 1)), light((0, -5, -2, 1), ambient=(.1, .1, .1))]),
+         30, cam=(64, 40, 60.0))
+    # NaN shadow rays: a directional light with a zero vector -> normalize(0) = NaN start, direction 0; every sphere /
+    # box accepts the NaN time and `time >= 1 || time < 0` is false: blocked (shade_and_reflect_kernel.cl:197-209,229)
+    o, _ = random_scene(5, 4, 0, seed=51)
+    zero_dir = R.make_light(R.LightProperties((.2, .2, .2), (.6, .6, .6), (.8, .8, .8)), position=(0.0, 0.0, 0.0, 0.0))
+    for tag, ls in (("last", [light((6, 8, 2, 1)), zero_dir]), ("first", [zero_dir, light((6, 8, 2, 1))])):
+        for kernel in ("shade", "shade_and_reflect"):
+            save(f"nan_shadow_{tag}_{kernel}", kernel, o, R.lights_array(ls), 2, cam=(48, 32, 60.0))
+    # degenerate instances (what glm::inverse returns for a scale of 0: infinities / NaNs; and an all-zero 3x3 that
+    # gives t = 0/0 for EVERY ray), last and in the middle of the object list: a NaN time overwrites and is overwritten
+    base, l = random_scene(5, 3, 2, seed=52)
+    def degenerate(kind):
+        rec = obj(R.SPHERE, mat((.4, .4, .1), (.5, .5, .5), (.5, .5, .5), absorption=.6, shininess=6.0), (1.0, -0.5, -9.0))
+        rec = rec.copy()
+        inv = rec["mvInverse"].reshape(4, 4).copy()   # column-major: [c][r]
+        if kind == "inf":
+            inv[2, 2] = np.inf; inv[3, 2] = np.nan    # scale z = 0
+            rec["mv"].reshape(4, 4)[2, 2] = 0.0
+        else:
+            inv[:3, :3] = 0.0                         # singular but finite
+        rec["mvInverse"] = inv.reshape(16)
+        return rec
+    for kind in ("inf", "zero"):
+        for where in ("last", "middle"):
+            recs = list(base)
+            recs.insert(len(recs) if where == "last" else 4, degenerate(kind))
+            for kernel in ("shade", "shade_and_reflect"):
+                save(f"degenerate_{kind}_{where}_{kernel}", kernel, R.objects_array(recs), l, 2, cam=(48, 32, 60.0))
+
+
 if __name__ == "__main__":
-    main()
+    if not oracle.reference_available():
+        sys.exit("oracle/_ref is not built (needs /root/reference): run `make -C oracle` in the build container")
+    if "--round2" in sys.argv:
+        round2()   # only the fixtures added in round 2 (the others are unchanged)
+    else:
+        main()
+        round2()

@@ -82,7 +82,11 @@ def rgb_bits(a):
 
 def compare_frames(hip_out, oracle_out, atol=1e-5):
     """max |dRGB| over all pixels (the north_star's colour bar is 1e-5 absolute)."""
-    d = np.abs(hip_out[:, :3].astype(np.float64) - oracle_out[:, :3].astype(np.float64))
+    a, b = hip_out[:, :3].astype(np.float64), oracle_out[:, :3].astype(np.float64)
+    d = np.abs(a - b)
+    # a NaN channel (degenerate instances, NaN rays) must be a NaN on both sides; a one-sided NaN is an infinite error
+    both_nan = np.isnan(a) & np.isnan(b)
+    d = np.where(both_nan, 0.0, np.where(np.isnan(d), np.inf, d))
     return float(d.max()) if d.size else 0.0
 
 

@@ -6,6 +6,8 @@ from pathlib import Path
 
 import pytest
 
+import helpers  # noqa: F401  (registers the package under its importable name)
+
 ROOT = Path(__file__).resolve().parent.parent
 HEADER = ROOT / "include" / "hip_raytracer.h"
 

@@ -51,9 +51,10 @@ def _worker(rank, world, port, tile_rows, W, H, result_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tile_rows,W,H", [(2, 16, 12), (4, 16, 10)])  # even split; ragged last tile + uneven ranks
-def test_two_rank_gather_assembles_the_frame(tmp_path, tile_rows, W, H):
-    port = 29500 + (os.getpid() % 2000) + tile_rows
+@pytest.mark.parametrize("world,tile_rows,W,H", [(2, 2, 16, 12), (2, 4, 16, 10), (3, 2, 16, 14), (3, 8, 16, 12)])
+def test_gather_assembles_the_frame(tmp_path, world, tile_rows, W, H):
+    """even split; ragged last tile + uneven ranks; three ranks; a rank with no tile at all (2 tiles, 3 ranks)"""
+    port = 29500 + (os.getpid() % 2000) + tile_rows + 7 * world
     result = tmp_path / "result.txt"
-    mp.spawn(_worker, args=(2, port, tile_rows, W, H, str(result)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, tile_rows, W, H, str(result)), nprocs=world, join=True)
     assert result.read_text() == "ok"

@@ -5,7 +5,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from helpers import R, SCENES, camera
+from helpers import R, ROOT, SCENES, camera
 from opencl_raytracer_amd import ppm, scene_loader, sharding, synthetic
 
 
@@ -140,3 +140,14 @@ def test_shard_arithmetic():
     pieces[1] = np.concatenate([pieces[1], np.zeros((50, 4), np.float32)])  # padded to max_local like the gather does
     assert np.array_equal(sharding.assemble_frame(pieces, tile, n), frame[:n])
     assert np.array_equal(sharding.assemble_frame([frame], tile, n), frame[:n])
+
+
+def test_scene_files_are_what_the_generator_prints():
+    """scenes/*.txt (the inputs BASELINE's configs name) are emitted by scenes/make_scenes.py from a structured
+    description; the committed text must be exactly that."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_scenes", ROOT / "scenes" / "make_scenes.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for name in mod.SCENES:
+        assert (ROOT / "scenes" / f"{name}.txt").read_text() == mod.scene_text(name), name

@@ -1,0 +1,236 @@
+"""GPU: oracle-vs-HIP coverage at the sizes the numbers are quoted on (round 2).
+
+* BASELINE configs[3] (100 000 spheres, 32 lights, 4096 x 4096, depth 3): 4 608 pixels scattered over the WHOLE frame
+  (64 x 64 lattice + 512 random) against the CPU oracle - colour, primary t / index, reference ray count - through the
+  default path (screen tiles + grid walk), not only grid-vs-brute-force self-consistency.
+* configs[4]'s analytic base at 8192 x 8192: 1 024 scattered pixels + rows.
+* The reference's SHIPPED workload: 2560 x 1440, MAX_BOUNCES = 30 (OpenCL-Raytracer.cpp:31-33,75) on roundedCube.txt and
+  simpleScene.txt, both paths, sampled rows against the oracle.
+* Depths up to 30 in the randomised sweep; NaN shadow rays; degenerate instances.
+"""
+import numpy as np
+import pytest
+
+from helpers import R, SCENES, camera, compare_frames, random_scene, same_floats
+
+pytestmark = pytest.mark.gpu
+
+RGB_ATOL = 1e-5
+
+
+def hip(*a, **k):
+    from opencl_raytracer_amd.hip_raytracer import HIPRaytracer
+    return HIPRaytracer(*a, **k)
+
+
+def scattered_pixels(W, H, lattice, n_random, seed):
+    """`lattice` x `lattice` pixels spread evenly over the frame plus `n_random` uniformly random ones (fixed seed)."""
+    sx, sy = W // lattice, H // lattice
+    xs = (np.arange(lattice) * sx + sx // 2 - 1).astype(np.int64)
+    ys = (np.arange(lattice) * sy + sy // 2 - 1).astype(np.int64)
+    gx, gy = np.meshgrid(xs, ys)
+    rng = np.random.default_rng(seed)
+    px = np.concatenate([gx.ravel(), rng.integers(0, W, n_random)])
+    py = np.concatenate([gy.ravel(), rng.integers(0, H, n_random)])
+    return px, py
+
+
+def rays_of_pixels(W, H, px, py, fov=60.0):
+    """The reference's primary rays (OpenCL-Raytracer.cpp:18-26,68-72) of the given pixels, as a ray list."""
+    rays = np.zeros(len(px), dtype=R.RAY_DTYPE)
+    rays["start"][:, 3] = 1.0
+    rays["direction"][:, 0] = px.astype(np.float32) - np.float32(W) / np.float32(2)
+    rays["direction"][:, 1] = (np.float32(H) - py.astype(np.float32)) - np.float32(H) / np.float32(2)
+    rays["direction"][:, 2] = np.float32(camera.camera_z(H, fov))
+    return rays
+
+
+def test_rays_of_pixels_is_the_camera():
+    W, H = 96, 40
+    full = camera.primary_rays(W, H)
+    px, py = np.arange(W * H) % W, np.arange(W * H) // W
+    assert np.array_equal(rays_of_pixels(W, H, px, py).view(np.uint32), full.view(np.uint32))
+
+
+def test_config4_scattered_pixels_of_the_full_frame_vs_oracle(restatement):
+    from opencl_raytracer_amd import synthetic
+    objs, lights = synthetic.spheres_and_lights(100_000, 32)
+    W = H = 4096
+    z = float(camera.camera_z(H))
+    px, py = scattered_pixels(W, H, 64, 512, seed=4)
+    assert len(px) == 4608
+    rays = rays_of_pixels(W, H, px, py)
+    want = restatement[True].render("shade_and_reflect", objs, lights, rays, 3)
+    # the headline path: the whole 4096^2 frame, in-kernel pinhole rays, screen tiles + grid walk
+    with hip(objs, lights, None, 3, camera=(W, H, z)) as rt:
+        assert rt.stats().pinhole == 1
+        frame = rt.Render().reshape(H, W, 4)
+        t, idx = rt.render_aux()
+        assert rt.stats().wavefront == 1
+    got = frame[py, px]
+    assert compare_frames(got, want["out"]) <= RGB_ATOL
+    assert np.array_equal(np.any(got[:, :3] != 0, axis=1), np.any(want["out"][:, :3] != 0, axis=1))
+    assert np.array_equal(idx.reshape(H, W)[py, px], want["hit_index"])
+    assert same_floats(t.reshape(H, W)[py, px], want["hit_t"])
+    assert int((want["hit_index"] >= 0).sum()) > 4000   # the cloud covers nearly every pixel
+    # the same pixels as a ray list (grid walk for the primary rays too): identical bits, and the reference-equivalent
+    # ray count of exactly these work-items equals the oracle's (pins every secondary hit / miss)
+    with hip(objs, lights, rays, 3) as rt:
+        out = rt.Render()
+        st = rt.count_rays()
+    assert np.array_equal(out.view(np.uint32), np.ascontiguousarray(got).view(np.uint32))
+    assert st.rays_reference == want["rays_ref"] and st.hit_pixels == int((want["hit_index"] >= 0).sum())
+
+
+def test_config5_base_scattered_pixels_8192_vs_oracle(restatement):
+    import torch
+    from opencl_raytracer_amd import scene_loader
+    objs, lights = scene_loader.load_scene(str(SCENES / "roundedCube.txt"))
+    W = H = 8192
+    z = float(camera.camera_z(H))
+    # the object fills the middle of the frame: a lattice over the whole frame plus a dense one over the centre
+    px, py = scattered_pixels(W, H, 32, 256, seed=5)
+    cx, cy = scattered_pixels(2048, 2048, 16, 256, seed=6)
+    px, py = np.concatenate([px, cx + 3072]), np.concatenate([py, cy + 3072])
+    rays = rays_of_pixels(W, H, px, py)
+    want = restatement[True].render("shade_and_reflect", objs, lights, rays, 5)
+    assert int((want["hit_index"] >= 0).sum()) > 300
+    with hip(objs, lights, None, 5, camera=(W, H, z)) as rt:
+        out = torch.empty((W * H, 4), dtype=torch.float32, device="cuda")
+        rt.render_device(out.data_ptr())
+        torch.cuda.synchronize()
+        sel = torch.from_numpy(py * W + px).cuda()
+        got = out[sel].cpu().numpy()
+    assert compare_frames(got, want["out"]) <= RGB_ATOL
+    assert np.array_equal(np.any(got[:, :3] != 0, axis=1), np.any(want["out"][:, :3] != 0, axis=1))
+    with hip(objs, lights, rays, 5) as rt:
+        t, idx = rt.render_aux()
+        st = rt.count_rays()
+    assert np.array_equal(idx, want["hit_index"]) and same_floats(t, want["hit_t"]) and st.rays_reference == want["rays_ref"]
+
+
+@pytest.mark.parametrize("scene", ["roundedCube", "simpleScene"])
+def test_reference_shipped_workload_2560x1440_depth30(scene, restatement):
+    """main()'s hard-coded frame: 2560 x 1440, fov 60, MAX_BOUNCES = 30 (OpenCL-Raytracer.cpp:31-33,75)."""
+    from opencl_raytracer_amd import scene_loader
+    objs, lights = scene_loader.load_scene(str(SCENES / f"{scene}.txt"))
+    W, H, D = 2560, 1440, 30
+    z = float(camera.camera_z(H))
+    frames = {}
+    for path in ("monolithic", "wavefront"):
+        with hip(objs, lights, None, D, camera=(W, H, z), path=path) as rt:
+            frames[path] = rt.Render()
+            st = rt.count_rays()
+            assert st.wavefront == int(path == "wavefront")
+            frames[path + "_ref"] = st.rays_reference
+    assert np.array_equal(frames["monolithic"].view(np.uint32), frames["wavefront"].view(np.uint32))
+    assert frames["monolithic_ref"] == frames["wavefront_ref"]
+    full = frames["monolithic"].reshape(H, W, 4)
+    rows = [0, 300, 500, 640, 719, 720, 721, 800, 950, 1100, 1439]
+    total_ref = 0
+    for r in rows:
+        rays = camera.primary_rays(W, H, row_begin=r, row_end=r + 1)
+        want = restatement[True].render("shade_and_reflect", objs, lights, rays, D)
+        assert compare_frames(full[r], want["out"]) <= RGB_ATOL
+        assert np.array_equal(np.any(full[r][:, :3] != 0, axis=1), np.any(want["out"][:, :3] != 0, axis=1))
+        total_ref += want["rays_ref"]
+    assert np.any(full[720][:, :3] != 0)
+    # reference-equivalent ray count of those rows (depth-30 paths: every secondary hit / miss / exhaustion is pinned)
+    band = np.concatenate([camera.primary_rays(W, H, row_begin=r, row_end=r + 1) for r in rows])
+    for path in ("monolithic", "wavefront"):
+        with hip(objs, lights, band, D, path=path, raygen=False) as rt:
+            assert rt.count_rays().rays_reference == total_ref
+
+
+@pytest.mark.parametrize("seed", list(range(400, 416)))
+def test_randomised_deep_bounce_configurations_vs_oracle(seed, restatement):
+    """The randomised sweep of test_parity_gpu.py at depths 6..30 with reflective materials (absorption <= 0.7), so
+    that the unsigned-exhaustion branch (.cl:268,281) and ~32 wavefront rounds are really exercised."""
+    rng = np.random.default_rng(seed)
+    n_s, n_b = int(rng.integers(2, 20)), int(rng.integers(0, 12))
+    n_l = int(rng.integers(1, 4))
+    objs, lights = random_scene(n_s, n_b, n_l, seed=seed, absorption=float(rng.choice([0.05, 0.2, 0.5, 0.7])),
+                                spread=float(rng.uniform(2, 5)), zrange=(-16.0, -6.0), nonuniform=bool(rng.integers(0, 2)))
+    w, h = int(rng.integers(16, 64)), int(rng.integers(8, 36))
+    depth = int(rng.choice([6, 7, 8, 13, 29, 30, 30, 31]))
+    fused = bool(rng.integers(0, 2))
+    path = ["monolithic", "wavefront"][int(rng.integers(0, 2))]
+    rays = camera.primary_rays(w, h)
+    want = restatement[fused].render("shade_and_reflect", objs, lights, rays, depth)
+    with hip(objs, lights, rays, depth, fused=fused, path=path, literal=bool(rng.integers(0, 4) == 0),
+             grid=bool(rng.integers(0, 4) != 0)) as rt:
+        out = rt.Render()
+        t, idx = rt.render_aux()
+        st = rt.count_rays()
+    assert np.array_equal(idx, want["hit_index"]) and same_floats(t, want["hit_t"])
+    assert st.rays_reference == want["rays_ref"]
+    assert compare_frames(out, want["out"]) <= RGB_ATOL
+    assert want["rays_ref"] > 3 * int((want["hit_index"] >= 0).sum())   # paths are long
+
+
+def test_light_at_the_hit_point_and_zero_directional_light(restatement):
+    """A shadow ray with a NaN in it: every sphere / box accepts it with time = NaN and the reference's
+    `time >= 1 || time < 0` reports the light as blocked - on every path (the any-hit test used `t < 1`)."""
+    objs, _ = random_scene(6, 5, 0, seed=77, spread=3.0, zrange=(-14.0, -7.0))
+    props = R.LightProperties((.2, .2, .2), (.6, .6, .6), (.8, .8, .8))
+    lights = R.lights_array([R.make_light(props, position=(4.0, 6.0, 1.0, 1.0)), R.make_light(props, position=(0.0, 0.0, 0.0, 0.0))])
+    rays = camera.primary_rays(64, 48)
+    for kernel in ("shade", "shade_and_reflect"):
+        want = restatement[True].render(kernel, objs, lights, rays, 2)
+        assert int((want["hit_index"] >= 0).sum()) > 100
+        for path, grid, literal in (("monolithic", True, False), ("wavefront", True, False), ("wavefront", False, False),
+                                    ("monolithic", True, True)):
+            with hip(objs, lights, rays, 2, kernel=kernel, path=path, grid=grid, literal=literal) as rt:
+                out = rt.Render()
+                st = rt.count_rays()
+            assert compare_frames(out, want["out"]) <= RGB_ATOL, (kernel, path, grid, literal)
+            assert st.rays_reference == want["rays_ref"]
+
+
+def test_degenerate_instance_falls_back_to_the_literal_loops(restatement):
+    """An instance with a non-finite / singular mvInverse (scale 0) gives NaN hit times for finite rays; the
+    reference's result then depends on the object order. Such scenes are rendered literally (rt_create) and must equal
+    the oracle wherever the instance sits - also in a scene large enough for the grid path."""
+    from opencl_raytracer_amd import synthetic
+    objs, lights = synthetic.spheres_and_lights(600, 3)
+    rays = camera.crop_rays(4096, 4096, 2048 - 24, 2048 - 16, 48, 32)
+    for where in (len(objs), 300, 0):
+        bad = objs[:1].copy()
+        inv = bad["mvInverse"].reshape(4, 4).copy()
+        inv[:3, :3] = 0.0
+        bad["mvInverse"] = inv.reshape(1, 16)
+        scene = np.concatenate([objs[:where], bad, objs[where:]])
+        want = restatement[True].render("shade_and_reflect", scene, lights, rays, 3)
+        with hip(scene, lights, rays, 3) as rt:
+            out = rt.Render()
+            st = rt.count_rays()
+        assert compare_frames(out, want["out"]) <= RGB_ATOL, where
+        assert st.rays_reference == want["rays_ref"]
+
+
+@pytest.mark.parametrize("n_objs", [12, 600])
+def test_device_render_is_ordered_with_the_callers_stream(n_objs):
+    """ShardedHIPRaytracer.Render() hands the C ABI torch's current stream; handle 0 (torch's default
+    stream) must mean THAT stream, not a private one - the frame is consumed here without any device-wide
+    synchronisation, on the default stream and on a side stream, for the small-scene kernel and the grid path."""
+    import torch
+    from opencl_raytracer_amd import synthetic
+    from opencl_raytracer_amd.distributed import ShardedHIPRaytracer
+    objs, lights = synthetic.spheres_and_lights(n_objs, 3)
+    W, H = 512, 256
+    z = float(camera.camera_z(H))
+    with hip(objs, lights, None, 3, camera=(W, H, z)) as rt:
+        want = rt.Render()
+    srt = ShardedHIPRaytracer(objs, lights, None, 3, camera=(W, H, z), tile_rows=16)
+    try:
+        for _ in range(3):
+            srt.gatherer.local.zero_()                    # enqueued on the current stream, before the render
+            got = srt.Render().cpu().numpy()              # .cpu() is ordered on the current stream, nothing else waits
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            srt.gatherer.local.zero_()
+            got = srt.Render().cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    finally:
+        srt.close()

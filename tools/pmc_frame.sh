@@ -1,0 +1,27 @@
+#!/bin/bash
+# One frame of a bench workload under rocprofv3, four separate passes (MI355X_MICROARCH.md: FETCH_SIZE and WRITE_SIZE
+# cannot share a pass; counters never together with the kernel trace):
+#   1. --kernel-trace --stats          per-kernel durations
+#   2. --pmc FETCH_SIZE                3. --pmc WRITE_SIZE
+#   4. --pmc SQ_* (instruction issue)
+# -> gpurun_out/frame_<workload>.json (+ the kernel-stats csv), stamped with the sha-256 of the library that ran.
+# Copy both into profiles/; bench.py only quotes the counters when the stamp matches the library it is running.
+# usage (GPU box, repo root):  bash tools/pmc_frame.sh cfg4
+set -e
+W=${1:-cfg4}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/frame_$W
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $R/bench.py --workload $W --steps 2 --warmup 1 --no-extra --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o p --output-format csv -- $BENCH > $OUT/trace.json 2> $OUT/trace.err
+echo "pass 1 (kernel trace) done"
+for C in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $C -d $OUT/$C -o p --output-format csv -- $BENCH > $OUT/$C.json 2> $OUT/$C.err
+  echo "pass $C done"
+done
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU -d $OUT/sq -o p --output-format csv -- $BENCH > $OUT/sq.json 2> $OUT/sq.err
+echo "pass SQ done"
+python3 $R/tools/pmc_frame.py $W $OUT > $R/gpurun_out/frame_$W.json
+cp $(ls $OUT/trace/*kernel_stats.csv | head -1) $R/gpurun_out/frame_${W}_kernel_stats.csv
+cat $R/gpurun_out/frame_$W.json
