@@ -135,6 +135,17 @@ def cpu_baseline(objs, lights, rays, kernel, depth, sample_desc):
             "sample": sample_desc, "seconds": best}
 
 
+def cpu_backend_baseline(objs, lights, rays, kernel, depth, sample_desc):
+    """The same sample on this repo's CPU backend behind IRaytracer (host/CPURaytracer.cpp, SURVEY.md 8 f4; std::thread,
+    every core) - the product's own no-GPU backend, not test infrastructure."""
+    from opencl_raytracer_amd.cpu_raytracer import CPURaytracer
+    rt = CPURaytracer(objs, lights, rays, depth, kernel=kernel, threads=host_cores())
+    rt.Render()
+    return {"value": rt.rays_traced / rt.seconds / 1e6, "unit": "Mrays/s", "cores": rt.threads_used, "kind": "backend",
+            "sample": sample_desc, "seconds": rt.seconds,
+            "what": "CPURaytracer : IRaytracer (host/CPURaytracer.cpp), every ray against every object like the reference's kernels"}
+
+
 def measure_brute_force_window(device_index, edge):
     """The brute-force traversal (every object for every ray: packed-pair stream, RT_FLAG_NO_GRID) on the centred
     edge x edge window of the cfg4 grid - the kernel that is measured against the FP32 VALU roofline."""
@@ -421,6 +432,7 @@ def main():
                 sample = camera.primary_rays(W, H, row_begin=H // 2 - rows // 2, row_end=H // 2 + rows // 2)
                 sdesc = f"centre {rows} rows of the {W}x{H} ray grid, same scene"
             out["cpu_baseline"] = cpu_baseline(objs, lights, sample, kernel, depth, sdesc)
+            out["cpu_backend"] = cpu_backend_baseline(objs, lights, sample, kernel, depth, sdesc)
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -63,7 +63,10 @@ typedef enum rt_kernel {
 #define RT_FLAG_UNFUSED   0x1u /* arithmetic of an OpenCL device WITHOUT fma contraction (x86 baseline); default
                                   is the contraction the OpenCL front-end marks (llvm.fmuladd -> fma)          */
 #define RT_FLAG_LITERAL   0x2u /* trace every ray the reference traces (no exact eliminations: any-hit shadow
-                                  early-out, backward light scan, dead reflection ray). Results are identical */
+                                  early-out, backward light scan, dead reflection ray). Results are identical.
+                                  rt_create sets it by itself for a scene with a DEGENERATE instance (non-finite or
+                                  singular mvInverse): its NaN hit times make the reference's result depend on the
+                                  order of the object loop, which only the literal loops reproduce               */
 #define RT_FLAG_NO_RAYGEN 0x4u /* never replace an uploaded pinhole ray grid by in-kernel generation            */
 #define RT_FLAG_WAVEFRONT  0x8u  /* force the large-scene path (separate traversal / shading kernels)          */
 #define RT_FLAG_NO_GRID    0x20u /* large-scene path: test every object for every ray (no conservative grid culling);
@@ -113,9 +116,13 @@ uint64_t rt_local_rays(const rt_context* ctx);
  * The buffer is overwritten by the next call and freed by rt_destroy. */
 int rt_render(rt_context* ctx, const float** out);
 
-/* Asynchronous render into caller-provided DEVICE memory (same element layout) on a caller-provided HIP stream
- * (hipStream_t passed as void*; NULL = the context's own stream). The small-scene path does not synchronise the
- * host; the large-scene path synchronises the stream once per trace round (a handful per frame). */
+/* Render into caller-provided DEVICE memory (same element layout) on a caller-provided HIP stream (hipStream_t passed
+ * as void*). NULL is the LEGACY DEFAULT stream - what a host framework's "current stream" handle is when it is on its
+ * default stream (torch: cuda_stream == 0) - so the frame is always ordered with the caller's own work on that stream;
+ * it is never a private stream of the context. The small-scene path does not synchronise the host. The large-scene
+ * path keeps its round loop on the device (queue lengths never travel to the host inside a round) and synchronises
+ * the stream once per batch of rounds - once per frame in the normal case. The calling thread's current device is
+ * left as it was. */
 int rt_render_device(rt_context* ctx, void* d_out, void* hip_stream);
 
 /* Optional per-work-item primary-hit record of the NEXT render: t (float) and winning object index

@@ -344,6 +344,9 @@ constexpr uint32_t kTicketStride = 16;   // one counter per 64-byte line
 constexpr uint32_t kTicketWords = 16u * kTicketStride;  // room for up to 16 regions per launch
 constexpr uint32_t kTicketBase = 16;     // counts[16 ..]: closest-hit launch, counts[16 + kTicketWords ..]: shadow launch
 
+#ifndef RT_WALK_DEDUPE
+#define RT_WALK_DEDUPE 1   // an object met again in the next cell is not parked / tested twice
+#endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 16  // new rays are handed out once this many lanes are idle (setting a ray up is ~150 instructions)
 #endif
@@ -424,7 +427,8 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
     int idx = -1;
     bool cur_sphere = false;
     bool pend = false;     // a candidate that passed the pre-test and awaits the exact test
-    uint32_t pend_e = 0;
+    uint32_t pend_k = 0;   // ... its object, and the object of the last exact test: an object is registered in every cell its
+    uint32_t done_k = 0xffffffffu;  // sphere reaches, so a ray meets it again in the next cell(s) - once is enough
 
     for (;;) {
         // ---- hand out rays to idle lanes ----
@@ -438,7 +442,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 pix = queue[mine];
                 ray = ANY ? load_ray(w, pix, kSlotShadow) : closest_ray(w, pix, w.first_round != 0u);
                 ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
-                T = kMaxFloat; idx = -1; cur_sphere = false; pend = false;
+                T = kMaxFloat; idx = -1; cur_sphere = false; pend = false; done_k = 0xffffffffu;
                 bool done = false;
                 for (uint32_t a = 0; a < g.n_always && !done; ++a) {  // objects every ray must test (usually none)
                     const int k = (int)g.always[a];
@@ -483,11 +487,18 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         // ---- phase B: pre-test one candidate (also for a lane that has just fetched a non-empty cell) ----
         if (st == 2) {
             const float4 bound = g.entry_sphere[e];
-            const bool pass = !misses_bounding_sphere(bound, ray, dd, g.pretest_alpha);
+            bool pass = !misses_bounding_sphere(bound, ray, dd, g.pretest_alpha);
+            uint32_t k = 0u;
+            if (pass) {  // the same object again (parked, or tested a cell ago)? its result is known or on its way
+                k = g.entries[e];
+#if RT_WALK_DEDUPE
+                if (k == done_k || (pend && k == pend_k)) pass = false;
+#endif
+            }
             if (pass && pend) {
                 blocked = true;  // one parking slot: wait for the exact tests
             } else {
-                if (pass) { pend = true; pend_e = e; }
+                if (pass) { pend = true; pend_k = k; }
                 ++e;
                 if (e == e1) advance = true;
             }
@@ -512,16 +523,16 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 ((uint32_t)__popcll(stuck) << RT_DEFER_STUCK_SHIFT) >= n_live) {
                 if (STATS && lane == 0u) ++s_flush;
                 if (pend) {
-                    const int pend_k = (int)g.entries[pend_e];
                     float t;
                     bool sphere;
                     const bool cand = lane_candidate<FUSED, true, TRI>(hot + pend_k, ray, t, sphere);
                     if (STATS) ++tested;
                     pend = false;
+                    done_k = pend_k;
                     if (ANY) {
                         if (cand && !(t >= 1.f)) { U(w, F_RES_ANY, pix) = 0u; st = 0; }
                     } else if (cand) {
-                        closest_take(t, pend_k, sphere, T, idx, cur_sphere);
+                        closest_take(t, (int)pend_k, sphere, T, idx, cur_sphere);
                     }
                 }
             }

@@ -1,12 +1,15 @@
 // scene_tool.cpp - the reference's main() without the window (OpenCL-Raytracer.cpp:28-104):
 //   scene_tool records <scene.txt> <out.bin>          parse the scene, dump the device records (no GPU needed)
-//   scene_tool render  <scene.txt> <W> <H> <D> <out.ppm> [z-bits]   parse, build rays, render on the GPU, write a PPM
+//   scene_tool render  <scene.txt> <W> <H> <D> <out.ppm> [z-bits|-] [hip|cpu]
+//                       parse, build rays, render, write a PPM. Backend: `hip` (default) = HIPRaytracer on the GPU;
+//                       `cpu` = CPURaytracer, no GPU (the reference's main() has both lines, OpenCL-Raytracer.cpp:74-75)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
 
+#include "CPURaytracer.hpp"
 #include "HIPRaytracer.hpp"
 #include "PPMExporter.hpp"
 #include "SceneLoader.hpp"
@@ -51,13 +54,16 @@ int main(int argc, char** argv) {
         float fov = rtm::radians(60.f);
         fov *= 0.5f;
         float z = -((height / 2.0f) / tanf(fov));
-        if (argc > 7) { const uint32_t bits = (uint32_t)std::strtoul(argv[7], nullptr, 16); std::memcpy(&z, &bits, 4); }
+        if (argc > 7 && std::strcmp(argv[7], "-") != 0) { const uint32_t bits = (uint32_t)std::strtoul(argv[7], nullptr, 16); std::memcpy(&z, &bits, 4); }
+        const bool cpu = argc > 8 && std::strcmp(argv[8], "cpu") == 0;
         std::vector<Ray3D> rays;
         rays.reserve((size_t)width * height);
         for (int jj = 0; jj < height; ++jj)
             for (int ii = 0; ii < width; ++ii)
                 rays.emplace_back(rtm::vec3(0, 0, 0), rtm::vec3((float)ii - width / 2.0f, (float)(height - jj) - height / 2.0f, z));
-        std::unique_ptr<IRaytracer> raytracer(new HIPRaytracer(objects, lights, rays, depth));
+        std::unique_ptr<IRaytracer> raytracer;
+        if (cpu) raytracer.reset(new CPURaytracer(objects, lights, rays, depth));
+        else raytracer.reset(new HIPRaytracer(objects, lights, rays, depth));
         cl_float4* pixels = raytracer->Render();
         PPMExporter::ExportP3(argv[6], (size_t)width, (size_t)height, PPMExporter::RGBAtoRGB(reinterpret_cast<const float*>(pixels), (size_t)width * height));
         std::printf("wrote %s\n", argv[6]);

@@ -65,3 +65,17 @@ def test_cpp_loader_errors(tool, tmp_path, text, needle, code):
 def test_cpp_loader_missing_file(tool, tmp_path):
     res = subprocess.run([str(tool), "records", "/nonexistent/scene.txt", str(tmp_path / "o.bin")], capture_output=True, text=True)
     assert res.returncode == 2 and "could not be found" in res.stdout
+
+
+def test_config1_ppm_known_answer_on_the_cpu_backend(tool, tmp_path):
+    """BASELINE configs[0] (simpleSphere.txt at 256x256 -> PPM, the no-GPU plumbing / diff harness) end to end in C++:
+    SceneLoader -> primary rays -> `new CPURaytracer(...)` through the IRaytracer base -> PPMExporter. The P3 file must
+    be the known answer of the reference's own kernels (397 825 bytes, md5 28365bd1...)."""
+    import hashlib
+    out = tmp_path / "cfg1.ppm"
+    res = subprocess.run([str(tool), "render", str(SCENES / "simpleSphere.txt"), "256", "256", "3", str(out), "-", "cpu"],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    data = out.read_bytes()
+    assert len(data) == 397825 and hashlib.md5(data).hexdigest() == "28365bd12a502710be0c9a9a1a8057a9"
+    assert data.splitlines()[3 + 128 * 256 + 128] == b"76 95 136"
