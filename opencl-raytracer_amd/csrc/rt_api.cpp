@@ -898,6 +898,8 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "objs/lights is NULL with a non-zero count");
     if (flags & ~(RT_FLAG_UNFUSED | RT_FLAG_LITERAL | RT_FLAG_NO_RAYGEN | RT_FLAG_WAVEFRONT | RT_FLAG_MONOLITHIC | RT_FLAG_NO_GRID))
         return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "unknown flag bits");
+    if (n_lights >= (1u << 22))  // the large-scene path keeps a pixel's light index in 22 bits of its phase word
+        return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "more than 4 194 303 lights");
     if ((flags & RT_FLAG_WAVEFRONT) && (flags & RT_FLAG_MONOLITHIC))
         return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "RT_FLAG_WAVEFRONT and RT_FLAG_MONOLITHIC are exclusive");
 

@@ -25,26 +25,36 @@
 
 namespace rt {
 
-// ---- per-pixel state, struct-of-arrays: field f of pixel i at st[f * n + i] ------------------------------------
+// ---- per-pixel state ------------------------------------------------------------------------------------------------
+// Two 32-byte ray records per pixel (store_ray), then 16-byte BLOCKS of four fields, each block an array over the
+// pixels (field f of pixel i at st[16 n + (f - 16 & ~3) n + 4 i + (f & 3)]): the fields a resume step reads or writes
+// together sit in one block, so a lane moves them with ONE 16-byte access and a wave with one 1-KB request, instead of
+// four 256-byte requests to four arrays (the kernel is bound by the memory system, not by its arithmetic). The default
+// shade_and_reflect flow touches the first four blocks only; the rest belongs to literal mode, the `shade` kernel and
+// stale-specular light scans.
 enum : uint32_t {
     F_SX, F_SY, F_SZ, F_SW, F_DX, F_DY, F_DZ, F_DW,          // closest-hit ray in flight (primary / reflection): ONE 32-byte record per pixel
     F_A0, F_A1, F_A2, F_A3, F_A4, F_A5, F_A6, F_A7,          // shadow ray in flight: a second 32-byte record (store_ray, slot 1)
-    F_RES_T, F_RES_I,                                          // closest-hit result: t / index
-    F_RES_ANY,                                                 // shadow-ray result: 1 lit, 0 occluded
-    F_PX, F_PY, F_PZ, F_PW, F_NX, F_NY, F_NZ, F_RX, F_RY, F_RZ, F_HIDX,  // hit being shaded
-    F_LI,                                                      // light index of the shadow ray in flight
-    F_AR, F_AG, F_AB, F_DR, F_DG, F_DB, F_SR, F_SG, F_SB,      // light-loop terms carried between rounds
-    F_CR, F_CG, F_CB,                                          // forward (literal / shade kernel) colour
-    F_ABR, F_ABG, F_ABB, F_RR, F_RG, F_RB, F_AP, F_BOUNCES,    // shade_and_reflect pixel state
-    F_PHASE,
+    F_PX, F_PY, F_PZ, F_HIDX,                                  // hit being shaded: view-space point, object
+    F_NX, F_NY, F_NZ, F_PHASE,                                 // ... its normal; phase word (phase | flags | light index << 10)
+    F_ABR, F_ABG, F_ABB, F_AP,                                 // shade_and_reflect: absorbColor, absorptionPercent
+    F_RES_T, F_RES_I, F_RES_ANY, F_BOUNCES,                    // trace results (closest: t / index; shadow: 1 lit, 0 blocked); bounces left
+    F_RX, F_RY, F_RZ, F_PW,                                    // reflection vector and point.w (only when the ray does not leave with the hit)
+    F_RR, F_RG, F_RB, F_SPARE,                                 // reflectColor across a reflection trace (literal mode)
+    F_AR, F_AG, F_AB, F_DR, F_DG, F_DB, F_SR, F_SG,            // light-loop terms carried between rounds
+    F_SB, F_CR, F_CG, F_CB,                                    // ... and the forward (literal / shade kernel) colour
     F_COUNT
 };
+static_assert(F_COUNT % 4 == 0 && F_PX == 16, "blocks of four after the two ray records");
 enum : uint32_t { PH_DONE = 0, PH_PRIMARY = 1, PH_SHADOW_PRIMARY = 2, PH_SHADOW_REFLECT = 3, PH_REFLECT = 4 };
 // flag on the phase word: the reflection ray that leaves the hit being shaded is already in flight / traced (its ray
 // in slot 0, its result in F_RES_T / F_RES_I) - see begin_shade
 constexpr uint32_t PH_FLAG_REFLECTION_SENT = 0x100u;
 // ... and it has not been traced yet (set for exactly the round that follows its emission; wf_finish needs to know)
 constexpr uint32_t PH_FLAG_REFLECTION_PENDING = 0x200u;
+// the light whose shadow ray is in flight rides in the same word
+constexpr uint32_t kPhaseLightShift = 10;
+static_assert(kPhaseLightShift == 10, "rt_create limits the light count to 2^22 - 1");
 
 // Round state, in device memory (WavefrontBuffers::counts). The host enqueues a frame's rounds WITHOUT waiting for the
 // queue lengths: every kernel of a round reads them from here (resolve_round) and a one-block kernel between rounds
@@ -104,9 +114,19 @@ __device__ __forceinline__ uint64_t pixel_of(const RenderParams& p, uint64_t t) 
     return (uint64_t)(((trow << 3) + (within >> 3)) * p.width + (tcol << 3) + (within & 7u));
 }
 
-__device__ __forceinline__ float& F(const WfParams& w, uint32_t f, uint64_t i) { return w.st[(uint64_t)f * w.rp.n_local + i]; }
+__device__ __forceinline__ uint64_t field_at(const WfParams& w, uint32_t f, uint64_t i) {
+    return (uint64_t)(f & ~3u) * w.rp.n_local + 4u * i + (f & 3u);  // (f >= 16: block (f - 16) / 4 behind the 16 n ray words)
+}
+__device__ __forceinline__ float& F(const WfParams& w, uint32_t f, uint64_t i) { return w.st[field_at(w, f, i)]; }
 __device__ __forceinline__ uint32_t& U(const WfParams& w, uint32_t f, uint64_t i) {
-    return reinterpret_cast<uint32_t*>(w.st)[(uint64_t)f * w.rp.n_local + i];
+    return reinterpret_cast<uint32_t*>(w.st)[field_at(w, f, i)];
+}
+// whole blocks (16-byte aligned: hipMalloc'ed base, every block starts at a multiple of 4 floats)
+__device__ __forceinline__ float4 load_block(const WfParams& w, uint32_t f0, uint64_t i) {
+    return *reinterpret_cast<const float4*>(w.st + field_at(w, f0, i));
+}
+__device__ __forceinline__ void store_block(const WfParams& w, uint32_t f0, uint64_t i, float4 v) {
+    *reinterpret_cast<float4*>(w.st + field_at(w, f0, i)) = v;
 }
 
 // A ray in flight is the one record the trace kernels read per lane at scattered pixel ids (a lane takes a new
@@ -127,21 +147,20 @@ __device__ __forceinline__ Ray load_ray(const WfParams& w, uint64_t i, uint32_t 
     r.dx = d.x; r.dy = d.y; r.dz = d.z; r.dw = d.w;
     return r;
 }
-// (the reflection vector is only kept when the reflection ray has not been sent with the hit - begin_shade_lit)
-__device__ __forceinline__ void store_hit(const WfParams& w, uint64_t i, const HitRec& h, bool with_reflection) {
-    F(w, F_PX, i) = h.px; F(w, F_PY, i) = h.py; F(w, F_PZ, i) = h.pz; F(w, F_PW, i) = h.pw;
-    F(w, F_NX, i) = h.nx; F(w, F_NY, i) = h.ny; F(w, F_NZ, i) = h.nz;
-    if (with_reflection) { F(w, F_RX, i) = h.rx; F(w, F_RY, i) = h.ry; F(w, F_RZ, i) = h.rz; }
-    U(w, F_HIDX, i) = (uint32_t)h.index;
+// The hit being shaded. Its point and normal are rewritten with the phase word (which carries the light index) by
+// emit_shadow: two 16-byte stores. The reflection vector and point.w are only kept when the reflection ray has not
+// been sent with the hit (begin_shade_lit).
+__device__ __forceinline__ void store_hit_extra(const WfParams& w, uint64_t i, const HitRec& h) {
+    store_block(w, F_RX, i, make_float4(h.rx, h.ry, h.rz, h.pw));
 }
-__device__ __forceinline__ HitRec load_hit(const WfParams& w, uint64_t i, bool with_reflection) {
-    HitRec h;
-    h.px = F(w, F_PX, i); h.py = F(w, F_PY, i); h.pz = F(w, F_PZ, i); h.pw = F(w, F_PW, i);
-    h.nx = F(w, F_NX, i); h.ny = F(w, F_NY, i); h.nz = F(w, F_NZ, i);
-    h.rx = h.ry = h.rz = 0.f;
-    if (with_reflection) { h.rx = F(w, F_RX, i); h.ry = F(w, F_RY, i); h.rz = F(w, F_RZ, i); }
-    h.index = (int)U(w, F_HIDX, i);
-    return h;
+// trace results: (t, index) of a closest-hit ray as one 8-byte store / load, the shadow flag next to them
+__device__ __forceinline__ void store_closest_result(const WfParams& w, uint64_t i, float T, int idx) {
+    *reinterpret_cast<float2*>(w.st + field_at(w, F_RES_T, i)) = make_float2(T, __uint_as_float((uint32_t)idx));
+}
+__device__ __forceinline__ void load_closest_result(const WfParams& w, uint64_t i, float& T, int& idx) {
+    const float2 r = *reinterpret_cast<const float2*>(w.st + field_at(w, F_RES_T, i));
+    T = r.x;
+    idx = (int)__float_as_uint(r.y);
 }
 
 // append pixel i to a queue (wave-aggregated by the compiler: one atomic per wave per call site)
@@ -236,10 +255,10 @@ __device__ __forceinline__ bool begin_pixel(const WfParams& w, uint64_t i) {
         else reinterpret_cast<float4*>(p.out)[px] = make_float4(0.f, 0.f, 0.f, 1.0f);
         if (p.aux_t) p.aux_t[px] = kMaxFloat;
         if (p.aux_index) p.aux_index[px] = -1;
-        U(w, F_PHASE, i) = PH_DONE;
+        store_block(w, F_NX, i, make_float4(0.f, 0.f, 0.f, __uint_as_float(PH_DONE)));
         return false;
     }
-    U(w, F_PHASE, i) = PH_PRIMARY;
+    store_block(w, F_NX, i, make_float4(0.f, 0.f, 0.f, __uint_as_float(PH_PRIMARY)));  // (a whole block: full lines instead of strided words)
     return true;
 }
 
@@ -255,8 +274,7 @@ __global__ __launch_bounds__(256) void wf_trace_closest(const WfParams wk) {
     float T = kMaxFloat;
     int idx = -1;
     closest_hit<FUSED, DW0>(w.rp.scene.pairs, w.rp.scene.n_pairs, ray, T, idx);
-    F(w, F_RES_T, i) = T;
-    U(w, F_RES_I, i) = (uint32_t)idx;
+    store_closest_result(w, i, T, idx);
     const unsigned long long lanes = (unsigned long long)__popcll(__ballot(true));
     if (w.count_rays && (threadIdx.x & 63u) == 0u)  // 2 tests per pair for every ray of the wave
         atomicAdd(&w.rp.counters->tests, 2ull * w.rp.scene.n_pairs * lanes);
@@ -317,8 +335,7 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams wk)
     } else {
         closest_hit_grid<FUSED, true>(w.grid, p.scene.hot, ray, T, idx, tested);
     }
-    F(w, F_RES_T, i) = T;
-    U(w, F_RES_I, i) = (uint32_t)idx;
+    store_closest_result(w, i, T, idx);
     if (w.count_rays) atomicAdd(&w.rp.counters->tests, (unsigned long long)tested);
 }
 
@@ -460,7 +477,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 wk = lean_walk(g, w0);
                 if (done || !w0.alive) {  // occluded by an always-object, or the ray misses the grid box
                     if (ANY) U(w, F_RES_ANY, pix) = (done || nan_shadow_blocked(w.rp.scene, ray)) ? 0u : 1u;
-                    else { F(w, F_RES_T, pix) = T; U(w, F_RES_I, pix) = (uint32_t)idx; }
+                    else store_closest_result(w, pix, T, idx);
                 } else {
                     st = 1;
                 }
@@ -540,7 +557,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         // ---- a finished walk with nothing parked: the ray is done ----
         if (st == 3 && !pend) {
             if (ANY) U(w, F_RES_ANY, pix) = 1u;  // nothing in the way
-            else { F(w, F_RES_T, pix) = T; U(w, F_RES_I, pix) = (uint32_t)idx; }
+            else store_closest_result(w, pix, T, idx);
             st = 0;
         }
     }
@@ -638,8 +655,7 @@ __global__ __launch_bounds__(256) void wf_trace_any_slice(const WfParams wk, con
 // has no coordinate beyond 0.4998 (tiny far boxes: 0/0 normal). The brute-force kernels reproduce that by
 // construction; for the grid path it is patched in here, where the result is consumed.
 __device__ __forceinline__ void closest_result(const WfParams& w, uint64_t i, bool primary, float& T, int& idx) {
-    T = F(w, F_RES_T, i);
-    idx = (int)U(w, F_RES_I, i);
+    load_closest_result(w, i, T, idx);
     if (T == kMaxFloat && w.grid.enabled && !w.rp.scene.literal && w.rp.scene.nan_winner >= 0) {
         const Ray ray = closest_ray(w, i, primary);
         if (nan_ray_outcome(ray, w.rp.scene.nan_winner, w.rp.scene.nan_winner_sphere) == kNanRayTimeNaN) {
@@ -655,6 +671,8 @@ struct Ctx {
     unsigned long long traced, reference, hits;
     bool want_closest, want_any;  // the pixel queued a ray for the next round (appended by block_push at the end)
     uint32_t flags;               // PH_FLAG_* bits of the pixel's phase word
+    uint32_t li;                  // ... and its light index
+    float4 nblock;                // the block the phase word came in: normal of the hit being shaded
 };
 
 template <int KERNEL>
@@ -665,7 +683,7 @@ __device__ __forceinline__ void write_pixel(Ctx& c, float r, float g, float b) {
 
 // queue the shadow ray of light `li` for the hit `h` (its geometry is recomputed when the result arrives)
 template <bool FUSED>
-__device__ __forceinline__ void emit_shadow(Ctx& c, const HitRec& h, uint32_t li, uint32_t phase) {
+__device__ __forceinline__ void emit_shadow(Ctx& c, const HitRec& h, uint32_t li, uint32_t phase, bool new_hit) {
     const Scene& S = c.w.rp.scene;
     float nvx = h.nx, nvy = h.ny, nvz = h.nz;
     normalize3(nvx, nvy, nvz);
@@ -674,8 +692,8 @@ __device__ __forceinline__ void emit_shadow(Ctx& c, const HitRec& h, uint32_t li
     LightGeom g;
     light_geometry<FUSED>(S.lights[li], h, nvx, nvy, nvz, vvx, vvy, vvz, g);
     store_ray(c.w, c.i, g.shadow, kSlotShadow);
-    U(c.w, F_LI, c.i) = li;
-    U(c.w, F_PHASE, c.i) = phase;
+    if (new_hit) store_block(c.w, F_PX, c.i, make_float4(h.px, h.py, h.pz, __uint_as_float((uint32_t)h.index)));
+    store_block(c.w, F_NX, c.i, make_float4(h.nx, h.ny, h.nz, __uint_as_float(phase | (li << kPhaseLightShift))));
     c.want_any = true;
     c.traced += 1;
 }
@@ -696,7 +714,7 @@ __device__ __forceinline__ void begin_shade_lit(Ctx& c, const HitRec& h, bool pr
     uint32_t flag = 0u;
     // shade_and_reflect outside literal mode never needs the stored reflection vector: either the ray leaves now, or
     // loop_step() will decide - under this same condition - that there is none
-    store_hit(c.w, c.i, h, !(KERNEL == 2 && !S.literal));
+    if (!(KERNEL == 2 && !S.literal)) store_hit_extra(c.w, c.i, h);
     if (KERNEL == 2 && !S.literal && spec_bounces > 0u && spec_ap <= 0.999f) {
         Ray ray;
         reflection_ray<FUSED>(h, ray);
@@ -708,13 +726,13 @@ __device__ __forceinline__ void begin_shade_lit(Ctx& c, const HitRec& h, bool pr
     const bool forward = (KERNEL == 1) || S.literal;
     // the carried light-loop terms start at zero: resume_shadow() knows the first light of a scan and does not
     // read them, so nothing is written here
-    emit_shadow<FUSED>(c, h, forward ? 0u : S.n_lights - 1u, (primary ? PH_SHADOW_PRIMARY : PH_SHADOW_REFLECT) | flag);
+    emit_shadow<FUSED>(c, h, forward ? 0u : S.n_lights - 1u, (primary ? PH_SHADOW_PRIMARY : PH_SHADOW_REFLECT) | flag, true);
 }
 
 // ... or, without lights, go straight on (shade() returns black)
 template <int KERNEL, bool FUSED>
 __device__ __forceinline__ void begin_shade(Ctx& c, const HitRec& h, bool primary, uint32_t spec_bounces, float spec_ap) {
-    if (c.w.rp.scene.n_lights == 0) { store_hit(c.w, c.i, h, true); shade_done<KERNEL, FUSED>(c, h, primary, 0.f, 0.f, 0.f); return; }
+    if (c.w.rp.scene.n_lights == 0) { shade_done<KERNEL, FUSED>(c, h, primary, 0.f, 0.f, 0.f); return; }  // (h travels in registers)
     begin_shade_lit<KERNEL, FUSED>(c, h, primary, spec_bounces, spec_ap);
 }
 
@@ -724,8 +742,16 @@ template <int KERNEL, bool FUSED>
 __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
     const Scene& S = c.w.rp.scene;
     const uint64_t i = c.i;
-    const HitRec h = load_hit(c.w, i, !(KERNEL == 2 && !S.literal));
-    const uint32_t li = U(c.w, F_LI, i);
+    HitRec h;
+    {   // point + object, normal (came in with the phase word), and - where it is kept - the reflection vector
+        const float4 a = load_block(c.w, F_PX, i);
+        h.px = a.x; h.py = a.y; h.pz = a.z; h.index = (int)__float_as_uint(a.w);
+        h.nx = c.nblock.x; h.ny = c.nblock.y; h.nz = c.nblock.z;
+        h.rx = h.ry = h.rz = 0.f;
+        h.pw = 1.0f;
+        if (!(KERNEL == 2 && !S.literal)) { const float4 r = load_block(c.w, F_RX, i); h.rx = r.x; h.ry = r.y; h.rz = r.z; h.pw = r.w; }
+    }
+    const uint32_t li = c.li;
     const bool lit = U(c.w, F_RES_ANY, i) != 0u;
     const ColdObject* co = S.cold + h.index;
     const float4 amb = co->amb_absorb, dif = co->dif_shine, spec = co->spec_type;
@@ -763,7 +789,7 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
         if (li + 1u < S.n_lights) {
             F(c.w, F_SR, i) = sr; F(c.w, F_SG, i) = sg; F(c.w, F_SB, i) = sb;
             F(c.w, F_CR, i) = cr; F(c.w, F_CG, i) = cg; F(c.w, F_CB, i) = cb;
-            emit_shadow<FUSED>(c, h, li + 1u, phase);
+            emit_shadow<FUSED>(c, h, li + 1u, phase, false);
         } else {
             shade_done<KERNEL, FUSED>(c, h, primary, cr, cg, cb);
         }
@@ -794,7 +820,7 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
         F(c.w, F_AR, i) = ar; F(c.w, F_AG, i) = ag; F(c.w, F_AB, i) = ab;
         F(c.w, F_DR, i) = dr; F(c.w, F_DG, i) = dg; F(c.w, F_DB, i) = db;
         F(c.w, F_SR, i) = sr; F(c.w, F_SG, i) = sg; F(c.w, F_SB, i) = sb;
-        emit_shadow<FUSED>(c, h, li - 1u, phase);
+        emit_shadow<FUSED>(c, h, li - 1u, phase, false);
     } else {
         shade_done<KERNEL, FUSED>(c, h, primary, (ar + dr) + sr, (ag + dg) + sg, (ab + db) + sb);
     }
@@ -813,12 +839,13 @@ __device__ __forceinline__ void finish_reflect(Ctx& c, bool fused, float abr, fl
 
 // the state a pixel carries across a reflection trace
 __device__ __forceinline__ void store_loop_state(Ctx& c, float abr, float abg, float abb, float rr, float rg, float rb, float ap,
-                                                 uint32_t bounces) {
+                                                 uint32_t bounces, bool keep_reflect_color) {
     const uint64_t i = c.i;
-    F(c.w, F_ABR, i) = abr; F(c.w, F_ABG, i) = abg; F(c.w, F_ABB, i) = abb;
-    F(c.w, F_RR, i) = rr; F(c.w, F_RG, i) = rg; F(c.w, F_RB, i) = rb;
-    F(c.w, F_AP, i) = ap;
+    store_block(c.w, F_ABR, i, make_float4(abr, abg, abb, ap));
     U(c.w, F_BOUNCES, i) = bounces;
+    // reflectColor only has to survive a trace when the NEXT resume step may end the loop without shading another hit
+    // (PH_REFLECT); a ray that left with its hit is followed by a shading step that replaces it
+    if (keep_reflect_color) store_block(c.w, F_RR, i, make_float4(rr, rg, rb, 0.f));
 }
 
 // top of one iteration of `while (bounces-- > 0 && raycast(...) && absorptionPercent <= 0.999f)` (:268)
@@ -843,7 +870,7 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
         const Ray ray = load_ray(c.w, i, kSlotClosest);
         HitRec rh;
         materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
-        store_loop_state(c, abr, abg, abb, rr, rg, rb, ap, bounces);
+        store_loop_state(c, abr, abg, abb, rr, rg, rb, ap, bounces, false);
         const float ra = (1.f - ap) * S.cold[rh.index].amb_absorb.w;  // shade_done's update, ahead of time
         begin_shade_lit<2, FUSED>(c, rh, false, bounces, ap + ra);
         return;
@@ -851,7 +878,7 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
     Ray ray;
     reflection_ray<FUSED>(from, ray);
     store_ray(c.w, c.i, ray, kSlotClosest);
-    store_loop_state(c, abr, abg, abb, rr, rg, rb, ap, bounces);
+    store_loop_state(c, abr, abg, abb, rr, rg, rb, ap, bounces, true);
     U(c.w, F_PHASE, c.i) = PH_REFLECT;
     c.want_closest = true;
     c.traced += 1;
@@ -867,8 +894,9 @@ __device__ void shade_done(Ctx& c, const HitRec& h, bool primary, float cr, floa
         const float ap = S.cold[h.index].amb_absorb.w;
         loop_step<FUSED>(c, h, cr * ap, cg * ap, cb * ap, 0.f, 0.f, 0.f, ap, c.w.rp.max_bounces);
     } else {
-        float ap = F(c.w, F_AP, i);
-        float abr = F(c.w, F_ABR, i), abg = F(c.w, F_ABG, i), abb = F(c.w, F_ABB, i);
+        const float4 acc = load_block(c.w, F_ABR, i);
+        float ap = acc.w;
+        float abr = acc.x, abg = acc.y, abb = acc.z;
         const float ra = (1.f - ap) * S.cold[h.index].amb_absorb.w;
         abr = fma_<FUSED>(ra, cr, abr); abg = fma_<FUSED>(ra, cg, abg); abb = fma_<FUSED>(ra, cb, abb);
         ap = ap + ra;
@@ -882,9 +910,11 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
     const WfParams& w = c.w;
     const uint64_t i = c.i;
     const Scene& S = w.rp.scene;
-    const uint32_t word = U(w, F_PHASE, i);
+    c.nblock = load_block(w, F_NX, i);
+    const uint32_t word = __float_as_uint(c.nblock.w);
     const uint32_t phase = word & 0xffu;
-    c.flags = word & ~0xffu;
+    c.flags = word & (PH_FLAG_REFLECTION_SENT | PH_FLAG_REFLECTION_PENDING);
+    c.li = word >> kPhaseLightShift;
     if (phase == PH_PRIMARY) {
         float T;
         int idx;
@@ -912,10 +942,11 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
         float T;
         int idx;
         closest_result(w, i, false, T, idx);
-        const float ap = F(w, F_AP, i);
+        const float4 acc = load_block(w, F_ABR, i), rc = load_block(w, F_RR, i);
+        const float ap = acc.w;
         const uint32_t bounces = U(w, F_BOUNCES, i);
-        const float abr = F(w, F_ABR, i), abg = F(w, F_ABG, i), abb = F(w, F_ABB, i);
-        const float rr = F(w, F_RR, i), rg = F(w, F_RG, i), rb = F(w, F_RB, i);
+        const float abr = acc.x, abg = acc.y, abb = acc.z;
+        const float rr = rc.x, rg = rc.y, rb = rc.z;
         if (T == kMaxFloat || !(ap <= 0.999f)) {  // raycast() false, or the absorption test of the loop condition
             finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces);
         } else {
@@ -952,7 +983,7 @@ __global__ __launch_bounds__(kResumeThreads) __attribute__((amdgpu_waves_per_eu(
     if (blockIdx.x * kResumeThreads >= w.n_prev_closest + w.n_prev_any) return;  // the grid is sized for the most the queues can hold
     const uint32_t t = blockIdx.x * kResumeThreads + threadIdx.x;
     const uint32_t total = w.n_prev_closest + w.n_prev_any;
-    Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u};
+    Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u, 0u, make_float4(0.f, 0.f, 0.f, 0.f)};
     if (t < total) {
         c.i = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
         if (!duplicate_entry(w, t, c.i)) resume_pixel<KERNEL, FUSED>(c);
@@ -973,7 +1004,7 @@ __global__ __launch_bounds__(256) void wf_finish(const WfParams wk) {
     if (w.counts[RS_FINISH] != 1u) return;  // only once wf_advance has handed the rest of the frame over
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t total = w.n_prev_closest + w.n_prev_any;
-    Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u};
+    Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u, 0u, make_float4(0.f, 0.f, 0.f, 0.f)};
     uint32_t tested = 0;
     if (t < total) {
         c.i = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
@@ -991,8 +1022,7 @@ __global__ __launch_bounds__(256) void wf_finish(const WfParams wk) {
                     float T = kMaxFloat;
                     int idx = -1;
                     closest_hit_grid<FUSED, true>(w.grid, w.rp.scene.hot, ray, T, idx, tested);
-                    F(w, F_RES_T, c.i) = T;
-                    U(w, F_RES_I, c.i) = (uint32_t)idx;
+                    store_closest_result(w, c.i, T, idx);
                 }
                 c.want_closest = false;
                 c.want_any = false;

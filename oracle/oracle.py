@@ -113,10 +113,15 @@ def reference_available() -> bool:
 class Reference:
     """The reference's own kernels, compiled verbatim for the host (oracle/_ref)."""
 
-    def __init__(self, kernel, fused: bool = True):
+    def __init__(self, kernel, fused: bool = True, shim_variant: int = 0):
+        """shim_variant 1..3: the fused kernels linked against other conforming definitions of dot() / normalize()
+        (ref_shim.cl) - shade / shade_and_reflect only."""
         self.kernel_id = _kernel_id(kernel)
         name = {0: "hittest", 1: "shade", 2: "shade_and_reflect"}[self.kernel_id]
         flavour = "fused" if fused else "unfused"
+        if shim_variant:
+            assert fused and self.kernel_id in (1, 2)
+            flavour += f"_shim{int(shim_variant)}"
         path = REFDIR / f"libref_{name}_{flavour}.so"
         if not path.exists():
             raise FileNotFoundError(f"{path} (oracle/_ref only exists where /root/reference was present)")
