@@ -70,6 +70,12 @@ struct rt_context {
     uint32_t* d_grid_always = nullptr;
     float4* d_grid_entry_sphere = nullptr;
     std::vector<double> h_grid_spheres;     // per object: centre + grid radius (inf: always tested, < 0: never hit)
+    std::vector<float> h_grid_pre;          // per object: pre-test radius as the grid's entry spheres carry it
+    uint2* d_lt_range = nullptr;            // light tiles (rt_grid.h: LightTiles) for the last light's shadow rays
+    uint32_t* d_lt_entries = nullptr;
+    float4* d_lt_sphere = nullptr;
+    float* d_lt_key = nullptr;
+    rt::LightTiles light_tiles = {};
     uint32_t* d_tile_start = nullptr;       // screen tiles (64 x 8 pixels) -> objects a pinhole primary ray can reach
     uint32_t* d_tile_entries = nullptr;
     rt::ScreenTiles tiles = {};
@@ -445,6 +451,7 @@ int ensure_wavefront(rt_context* c) {
     RT_HIP(c, hipEventCreateWithFlags(&b.ev_join, hipEventDisableTiming));
     b.shadow_pairs = c->d_shadow_pairs;
     b.grid = c->grid;
+    b.light_tiles = c->light_tiles;
     b.capacity = n;
     return RT_OK;
 }
@@ -646,7 +653,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     const double diag = std::sqrt(ext[0] * ext[0] + ext[1] * ext[1] + ext[2] * ext[2]);
     if (!(diag > 0) || !std::isfinite(diag)) return RT_OK;
     // cell edge: about two cells per object in volume, at most 256 cells per axis
-    double cells_per_object = 2.0;
+    double cells_per_object = 3.0;  // (2: 22.3 ms per cfg4 frame, 3: 22.0, 4: 22.0 - since the shadow rays of the last light left the grid for the light tiles)
     if (const char* env = std::getenv("RT_GRID_CELLS_PER_OBJECT")) {  // tuning knob (results do not depend on it)
         const double v = std::atof(env);
         if (v > 0.01 && v < 1000.0) cells_per_object = v;
@@ -805,13 +812,15 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
             RT_HIP(c, hipMalloc((void**)&c->d_grid_entries, sizeof(uint32_t) * (total + 1)));
             RT_HIP(c, hipMalloc((void**)&c->d_grid_always, sizeof(uint32_t) * (always.size() + 1)));
             {   // per entry: the sphere the object was registered with (rounded outwards), for the kernels' pre-test
+                // pre-test radius per object, rounded away from zero; negative = "already holds the worst-case distance term"
+                c->h_grid_pre.resize(n);
+                for (uint32_t i = 0; i < n; ++i)
+                    c->h_grid_pre[i] = rpre[i] >= 0 ? std::nextafter((float)rpre[i], std::numeric_limits<float>::infinity())
+                                                    : std::nextafter((float)rpre[i], -std::numeric_limits<float>::infinity());
                 std::vector<float4> es(total);
                 for (size_t k = 0; k < total; ++k) {
                     const uint32_t i = entries[k];
-                    // pre-test radius, rounded away from zero; negative = "already holds the worst-case distance term"
-                    const float r = rpre[i] >= 0 ? std::nextafter((float)rpre[i], std::numeric_limits<float>::infinity())
-                                                 : std::nextafter((float)rpre[i], -std::numeric_limits<float>::infinity());
-                    es[k] = make_float4((float)sph[i].x, (float)sph[i].y, (float)sph[i].z, r);
+                    es[k] = make_float4((float)sph[i].x, (float)sph[i].y, (float)sph[i].z, c->h_grid_pre[i]);
                 }
                 RT_HIP(c, hipMalloc((void**)&c->d_grid_entry_sphere, sizeof(float4) * (total + 1)));
                 if (total) RT_HIP(c, hipMemcpy(c->d_grid_entry_sphere, es.data(), sizeof(float4) * total, hipMemcpyHostToDevice));
@@ -877,6 +886,165 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
         c->h_grid_spheres[4 * i] = sph[i].x; c->h_grid_spheres[4 * i + 1] = sph[i].y; c->h_grid_spheres[4 * i + 2] = sph[i].z;
         c->h_grid_spheres[4 * i + 3] = rg[i];
     }
+    return RT_OK;
+}
+
+// Light tiles (rt_grid.h: LightTiles): the objects a shadow ray towards the LAST positional light can meet, binned by
+// direction as seen from that light. shade_and_reflect's colour comes from the last light (Q1), so outside literal
+// mode nearly every shadow ray goes there; rays towards other lights (stale-specular scans) keep using the grid walk.
+// Needs: the conservative grid (its registration radii are the ones used here, + 1e-3 for the ray's own rounding: the
+// line of a shadow ray passes the light within ~1e-5), no always-tested objects, and an axis-aligned plane through the
+// light with every object strictly (by its radius + 0.05) on one side - else nothing is built and the grid walk serves.
+int build_light_tiles(rt_context* c, const rt_light* lights) {
+    c->light_tiles = rt::LightTiles{};
+    if (!c->grid.enabled || c->grid.n_always != 0 || c->kernel != RT_KERNEL_SHADE_AND_REFLECT || (c->flags & RT_FLAG_LITERAL) ||
+        c->n_lights == 0 || c->h_grid_spheres.empty() || c->h_grid_pre.size() != c->n_objs)
+        return RT_OK;
+    if (std::getenv("RT_NO_LIGHT_TILES")) return RT_OK;  // measurement knob
+    const uint32_t li = c->n_lights - 1u;
+    const float* lp = lights[li].position;
+    if (!(lp[3] != 0.f) || !std::isfinite(lp[0] + lp[1] + lp[2])) return RT_OK;  // directional (or garbage): no centre of projection
+    const double L[3] = {lp[0], lp[1], lp[2]};
+    const uint32_t n = c->n_objs;
+    const double inf = std::numeric_limits<double>::infinity();
+    constexpr double kPad = 1e-3, kFront = 0.05;
+    // projection axis: every registered object strictly in front of the plane through the light
+    int best_axis = -1;
+    double best_sign = 0, best_clear = 0;
+    for (int a = 0; a < 3; ++a)
+        for (double sg : {-1.0, 1.0}) {
+            double clear = inf;  // min over objects of (signed depth - radius)
+            for (uint32_t i = 0; i < n && clear > kFront; ++i) {
+                const double r = c->h_grid_spheres[4 * i + 3];
+                if (!(r >= 0) || r == inf) continue;
+                clear = std::min(clear, sg * (c->h_grid_spheres[4 * i + a] - L[a]) - (r + kPad));
+            }
+            if (clear > kFront && clear != inf && clear > best_clear) { best_clear = clear; best_axis = a; best_sign = sg; }
+        }
+    if (best_axis < 0) return RT_OK;
+    // light-local frame: z' = -sign * (p - L)[axis] (objects at z' < 0), x', y' = the other two components
+    const uint32_t az = (uint32_t)best_axis, ax = (az + 1u) % 3u, ay = (az + 2u) % 3u;
+    const double szn = -best_sign;
+    struct Rect { double u0, u1, v0, v1; };
+    std::vector<Rect> rect(n, Rect{1, -1, 1, -1});
+    double U0 = inf, U1 = -inf, V0 = inf, V1 = -inf;
+    auto span = [&](double cx, double cz, double r, double& lo, double& hi) -> bool {
+        // directions (x', z') through the origin that meet the disc (cx, cz; r), as x' / -z': tan of [phi - alpha, phi + alpha]
+        const double rho = std::sqrt(cx * cx + cz * cz);
+        if (!(rho > r)) return false;
+        const double phi = std::atan2(cx, -cz), alpha = std::asin(std::min(1.0, r / rho));
+        if (!(std::fabs(phi) + alpha < 1.5533)) return false;  // within 89 degrees of the axis, or no usable tangent
+        lo = std::tan(phi - alpha);
+        hi = std::tan(phi + alpha);
+        // + what the kernel's fp32 (u, v) of a ray can be off by (~3e-7 (1 + |u|)), 30 times over
+        lo -= 1e-5 * (1.0 + std::fabs(lo));
+        hi += 1e-5 * (1.0 + std::fabs(hi));
+        return true;
+    };
+    for (uint32_t i = 0; i < n; ++i) {
+        const double r0 = c->h_grid_spheres[4 * i + 3];
+        if (!(r0 >= 0) || r0 == inf) continue;  // can never be hit
+        const double r = r0 + kPad;
+        const double q[3] = {c->h_grid_spheres[4 * i] - L[0], c->h_grid_spheres[4 * i + 1] - L[1], c->h_grid_spheres[4 * i + 2] - L[2]};
+        const double qx = q[ax], qy = q[ay], qz = szn * q[az];
+        Rect rc;
+        if (!span(qx, qz, r, rc.u0, rc.u1) || !span(qy, qz, r, rc.v0, rc.v1)) return RT_OK;
+        rect[i] = rc;
+        U0 = std::min(U0, rc.u0); U1 = std::max(U1, rc.u1); V0 = std::min(V0, rc.v0); V1 = std::max(V1, rc.v1);
+    }
+    if (!(U1 > U0) || !(V1 > V0) || !std::isfinite(U0 + U1 + V0 + V1)) return RT_OK;
+    // tile count: ~1.6 sqrt(n) per axis, halved while the lists would hold more than 24 entries per object
+    uint32_t T = (uint32_t)std::min(1024.0, std::max(16.0, 1.6 * std::sqrt((double)n)));
+    std::vector<uint32_t> start, entries, fill;
+    uint64_t total = 0;
+    float u0f = 0, v0f = 0, inv_du = 0, inv_dv = 0;
+    auto tile_span = [&](double lo, double hi, float base, float inv, uint32_t& t0, uint32_t& t1) {
+        // the fp32 expression the kernel evaluates, in double, with 0.01 tile of slack for the kernel's own rounding of it
+        // (its (u, v) error is already inside the rectangle's padding; the product and the subtraction add < 1e-3 tile)
+        const double a = std::floor((lo - (double)base) * (double)inv - 0.01), b = std::floor((hi - (double)base) * (double)inv + 0.01);
+        t0 = (uint32_t)std::max(0.0, a);
+        t1 = (uint32_t)std::min((double)T - 1.0, std::max(0.0, b));
+    };
+    for (;;) {
+        const double du = (U1 - U0) / T * (1.0 + 1e-6), dv = (V1 - V0) / T * (1.0 + 1e-6);
+        u0f = std::nextafter((float)U0, -std::numeric_limits<float>::infinity());
+        v0f = std::nextafter((float)V0, -std::numeric_limits<float>::infinity());
+        inv_du = (float)(1.0 / du);
+        inv_dv = (float)(1.0 / dv);
+        start.assign((size_t)T * T + 1, 0);
+        total = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!(rect[i].u1 >= rect[i].u0)) continue;
+            uint32_t a0, a1, b0, b1;
+            tile_span(rect[i].u0, rect[i].u1, u0f, inv_du, a0, a1);
+            tile_span(rect[i].v0, rect[i].v1, v0f, inv_dv, b0, b1);
+            total += (uint64_t)(a1 - a0 + 1) * (b1 - b0 + 1);
+        }
+        if (total <= 24ull * n + 4096ull || T <= 16u) break;
+        T /= 2u;
+    }
+    if (total > 64ull * n + 4096ull || total > 0x7fffffffull) return RT_OK;  // objects too wide as seen from the light
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            for (size_t k = 0; k < (size_t)T * T; ++k) start[k + 1] += start[k];
+            entries.assign((size_t)total, 0);
+            fill.assign(start.begin(), start.end() - 1);
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!(rect[i].u1 >= rect[i].u0)) continue;
+            uint32_t a0, a1, b0, b1;
+            tile_span(rect[i].u0, rect[i].u1, u0f, inv_du, a0, a1);
+            tile_span(rect[i].v0, rect[i].v1, v0f, inv_dv, b0, b1);
+            for (uint32_t b = b0; b <= b1; ++b)
+                for (uint32_t a = a0; a <= a1; ++a) {
+                    if (pass == 0) start[(size_t)b * T + a + 1] += 1;
+                    else entries[fill[(size_t)b * T + a]++] = i;
+                }
+        }
+    }
+    std::vector<uint2> ranges((size_t)T * T);
+    for (size_t k = 0; k < ranges.size(); ++k) ranges[k] = make_uint2(start[k], start[k + 1] - start[k]);
+    // a tile's entries ordered by how far from the light the object starts: a ray's list ends at the first one that starts
+    // beyond its own origin (an occluder's hit point lies between origin and light, within the registration radius of its centre)
+    std::vector<float> key(n, 0.f);
+    for (uint32_t i = 0; i < n; ++i) {
+        const double r0 = c->h_grid_spheres[4 * i + 3];
+        if (!(r0 >= 0) || r0 == inf) continue;
+        const double q[3] = {c->h_grid_spheres[4 * i] - L[0], c->h_grid_spheres[4 * i + 1] - L[1], c->h_grid_spheres[4 * i + 2] - L[2]};
+        const double d = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) - (r0 + kPad);
+        key[i] = std::nextafter((float)(d * (1.0 - 1e-6)), -std::numeric_limits<float>::infinity());
+    }
+    for (size_t t = 0; t < ranges.size(); ++t)
+        std::sort(entries.begin() + start[t], entries.begin() + start[t + 1], [&](uint32_t a, uint32_t b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
+    std::vector<float4> es((size_t)total);
+    std::vector<float> ek((size_t)total);
+    for (size_t k = 0; k < (size_t)total; ++k) {
+        const uint32_t i = entries[k];
+        es[k] = make_float4((float)c->h_grid_spheres[4 * i], (float)c->h_grid_spheres[4 * i + 1], (float)c->h_grid_spheres[4 * i + 2], c->h_grid_pre[i]);
+        ek[k] = key[i];
+    }
+    RT_HIP(c, hipMalloc((void**)&c->d_lt_key, sizeof(float) * ((size_t)total + 1)));
+    if (total) RT_HIP(c, hipMemcpy(c->d_lt_key, ek.data(), sizeof(float) * (size_t)total, hipMemcpyHostToDevice));
+    RT_HIP(c, hipMalloc((void**)&c->d_lt_range, sizeof(uint2) * ranges.size()));
+    RT_HIP(c, hipMalloc((void**)&c->d_lt_entries, sizeof(uint32_t) * ((size_t)total + 1)));
+    RT_HIP(c, hipMalloc((void**)&c->d_lt_sphere, sizeof(float4) * ((size_t)total + 1)));
+    RT_HIP(c, hipMemcpy(c->d_lt_range, ranges.data(), sizeof(uint2) * ranges.size(), hipMemcpyHostToDevice));
+    if (total) {
+        RT_HIP(c, hipMemcpy(c->d_lt_entries, entries.data(), sizeof(uint32_t) * (size_t)total, hipMemcpyHostToDevice));
+        RT_HIP(c, hipMemcpy(c->d_lt_sphere, es.data(), sizeof(float4) * (size_t)total, hipMemcpyHostToDevice));
+    }
+    rt::LightTiles& lt = c->light_tiles;
+    lt.tile_range = c->d_lt_range;
+    lt.entries = c->d_lt_entries;
+    lt.entry_sphere = c->d_lt_sphere;
+    lt.entry_key = c->d_lt_key;
+    lt.lx = lp[0]; lt.ly = lp[1]; lt.lz = lp[2];
+    lt.u0 = u0f; lt.v0 = v0f; lt.inv_du = inv_du; lt.inv_dv = inv_dv;
+    lt.tiles_u = T; lt.tiles_v = T;
+    lt.ax = ax; lt.ay = ay; lt.az = az;
+    lt.sx = 1.f; lt.sy = 1.f; lt.sz = (float)szn;
+    lt.light = li;
+    lt.enabled = 1u;
     return RT_OK;
 }
 
@@ -1034,6 +1202,8 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
 #undef RT_TRY
     if (n_objs >= kWavefrontGridMinObjects || (flags & RT_FLAG_WAVEFRONT) || c->has_triangles) {
         rc = build_grid(c, static_cast<const rt_object_data*>(objs), n_objs);
+        if (rc != RT_OK) return bail(rc);
+        rc = build_light_tiles(c, static_cast<const rt_light*>(lights));
         if (rc != RT_OK) return bail(rc);
     }
     if (c->has_triangles && (!c->grid.enabled || (flags & (RT_FLAG_LITERAL | RT_FLAG_MONOLITHIC | RT_FLAG_NO_GRID)))) {
@@ -1214,6 +1384,10 @@ void rt_destroy(rt_context* c) {
     if (c->d_grid_entry_sphere) (void)hipFree(c->d_grid_entry_sphere);
     if (c->d_tile_start) (void)hipFree(c->d_tile_start);
     if (c->d_tile_entries) (void)hipFree(c->d_tile_entries);
+    if (c->d_lt_range) (void)hipFree(c->d_lt_range);
+    if (c->d_lt_entries) (void)hipFree(c->d_lt_entries);
+    if (c->d_lt_sphere) (void)hipFree(c->d_lt_sphere);
+    if (c->d_lt_key) (void)hipFree(c->d_lt_key);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->d_out) (void)hipFree(c->d_out);

@@ -68,6 +68,43 @@ struct ScreenTiles {
     uint32_t enabled;
 };
 
+// Light tiles: shadow rays towards ONE positional light (the last light - the one shade_and_reflect's colour comes from)
+// all lie on lines through that light, so "which objects can this ray meet" is a 2-D question in the light's own
+// perspective: objects are binned by the rectangle their registration sphere covers in gnomonic coordinates
+// (u, v) = (x', y') / -z' of the light-local frame (x', y', z' = a signed permutation of p - L in which every object lies
+// at z' < 0), and a ray looks up the one tile its origin falls in - no cell walk. Built on the host (rt_api.cpp:
+// build_light_tiles) when every object lies strictly on one side of an axis-aligned plane through the light; every
+// candidate still goes through the pre-test and the reference's exact test, so the answer is the brute-force loop's.
+struct LightTiles {
+    const uint2* __restrict__ tile_range;      // tiles_u * tiles_v x {first entry, count}
+    const uint32_t* __restrict__ entries;      // object indices
+    const float4* __restrict__ entry_sphere;   // parallel: centre (view space) + pre-test radius, as GridDesc::entry_sphere
+    const float* __restrict__ entry_key;       // parallel: distance from the light to the nearest point of the registration sphere;
+                                               // a tile's entries are sorted by it, and a ray's list ENDS at the first key beyond its origin
+    float lx, ly, lz;                          // the light
+    float u0, v0, inv_du, inv_dv;              // tile (iu, iv) covers u0 + iu / inv_du ...
+    uint32_t tiles_u, tiles_v;
+    uint32_t ax, ay, az;                       // light-local x', y', z' = component ax / ay / az of p - L ...
+    float sx, sy, sz;                          // ... times this sign
+    uint32_t light;                            // index of the light the structure is for
+    uint32_t enabled;
+};
+
+// tile of the ray whose ORIGIN is `s` (any point of the line through the light does): false = no object in that direction
+__device__ __forceinline__ bool light_tile_of(const LightTiles& lt, float sx, float sy, float sz, uint32_t& tile, float& dist) {
+    const float p[3] = {sx - lt.lx, sy - lt.ly, sz - lt.lz};
+    dist = __builtin_sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) * 1.000001f + 1.0e-4f;  // origin <-> light, rounded up
+    const float qx = lt.sx * (lt.ax == 0u ? p[0] : (lt.ax == 1u ? p[1] : p[2]));
+    const float qy = lt.sy * (lt.ay == 0u ? p[0] : (lt.ay == 1u ? p[1] : p[2]));
+    const float qz = lt.sz * (lt.az == 0u ? p[0] : (lt.az == 1u ? p[1] : p[2]));
+    if (!(qz < 0.f)) return false;  // (never for an origin on an object: they all lie at z' < 0, a margin away; NaN: caller)
+    const float inv = -1.0f / qz;
+    const float fu = (qx * inv - lt.u0) * lt.inv_du, fv = (qy * inv - lt.v0) * lt.inv_dv;
+    if (!(fu >= 0.f && fv >= 0.f && fu < (float)lt.tiles_u && fv < (float)lt.tiles_v)) return false;
+    tile = (uint32_t)fv * lt.tiles_u + (uint32_t)fu;
+    return true;
+}
+
 // order-free closest-hit update (see header comment); `cur_sphere` = the current winner is a sphere. Triangles
 // (extension) tie like boxes: the earlier object wins.
 __device__ __forceinline__ void closest_take(float t, int k, bool sphere, float& T, int& index, bool& cur_sphere) {

@@ -42,6 +42,7 @@ struct WavefrontBuffers {
     const HotPair* shadow_pairs = nullptr;         // size-sorted pair stream (owned by the context)
     GridDesc grid = {};                            // conservative grid (owned by the context); enabled = 0 -> brute force
     ScreenTiles tiles = {};                        // per-screen-tile object lists for pinhole primary rays
+    LightTiles light_tiles = {};                   // per-direction object lists for the shadow rays of the last light
     uint32_t* counts = nullptr;                    // device-side round state (queue lengths, hand-over flags) + run-ticket counters
     uint32_t* h_counts = nullptr;                  // 16 x uint32 pinned host mirror of the round state
     uint64_t capacity = 0;                         // n_local the buffers were sized for

@@ -82,6 +82,7 @@ struct WfParams {
     const HotPair* shadow_pairs;  // pair stream sorted by decreasing size, for order-free shadow tests
     GridDesc grid;                // conservative uniform grid (enabled = 0: brute force)
     ScreenTiles tiles;            // screen-tile object lists for pinhole primary rays
+    LightTiles ltiles;            // light tiles for the last light's shadow rays
     uint32_t n_prev_closest, n_prev_any;
     int kernel;
     uint32_t first_round;  // the closest-hit rays of this round are the primary rays (never stored: closest_ray())
@@ -350,11 +351,11 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams wk)
 // / pre-test / full test - so that the full test only runs with half the wave ready: 2x SLOWER, the extra trips
 // and ballots cost more than the better packing of the expensive phase saves.)
 #ifndef RT_SEGMENT
-#define RT_SEGMENT 128  // queue entries per run (64: 33.8 ms per cfg4 frame, 128: 32.2)
+#define RT_SEGMENT 256  // queue entries per run (round 2, with 8 ticket regions: 128: 20.4 ms per cfg4 frame, 256: 20.3, 512: 20.6+; one region: 128: 22.1, 256: 20.7, 1024: 22.1, 2048: 25.0)
 #endif
 constexpr uint32_t kSegment = RT_SEGMENT;
 #ifndef RT_TICKET_REGIONS
-#define RT_TICKET_REGIONS 1  // ticket counters per launch; 8 = one region of the queue per XCD (measured: 24.0 vs 24.0-24.3 ms per cfg4 frame - no gain, the walk is instruction-bound)
+#define RT_TICKET_REGIONS 8  // ticket counters per launch, one region of the queue per XCD: a single counter's returning atomics (~88 per microsecond) were costing 1.6 ms per cfg4 frame at 128-entry runs once the shadow rays had left the grid walk
 #endif
 constexpr uint32_t kTicketRegions = RT_TICKET_REGIONS;
 constexpr uint32_t kTicketStride = 16;   // one counter per 64-byte line
@@ -371,7 +372,7 @@ constexpr uint32_t kTicketBase = 16;     // counts[16 ..]: closest-hit launch, c
 #define RT_SKIP_CAP 2  // empty-space steps a lane takes per trip beyond the first (the other lanes wait for it; cfg5: 0: 94.7 ms, 2: 91.2, 6: 91.6, 12: 92.1)
 #endif
 #ifndef RT_DEFER_PENDING
-#define RT_DEFER_PENDING 16  // run the exact tests once this many lanes hold a candidate ...
+#define RT_DEFER_PENDING 8  // run the exact tests once this many lanes hold a candidate ... (8: 20.4, 16: 20.7, 28: 22.9 ms - fewer candidates wait since repeated objects are skipped)
 #endif
 #ifndef RT_DEFER_STUCK_SHIFT
 #define RT_DEFER_STUCK_SHIFT 2  // ... or once a quarter of the live lanes cannot move without theirs
@@ -393,7 +394,12 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
     // queue (= in the image), which is what keeps cells and objects in L2: drawing from 64 regions of the queue at
     // once cost 62 ms per cfg4 frame, from one 46.5. Ticket demand (~26 per microsecond) is far below what one
     // counter sustains (~88).
-    const uint32_t n_runs = (n_queue + kSegment - 1u) / kSegment;
+    // Run length: kSegment while the queue holds at least two such runs per launched wave; shorter (down to 64) for
+    // small queues - the tail of a frame, or one rank's share of it on a multi-GPU node - so that every wave still gets
+    // work and no wave ends the launch alone with a long run.
+    uint32_t seg = kSegment;
+    while (seg > 64u && n_queue < 2u * n_waves * seg) seg >>= 1;
+    const uint32_t n_runs = (n_queue + seg - 1u) / seg;
     const bool dynamic = n_runs > n_waves;
     uint32_t next = 0, seg_end = 0;  // wave-uniform cursor into the current run
     // Dynamic hand-out, XCD-affine: the queue is cut into kTicketRegions contiguous regions with one ticket counter
@@ -415,8 +421,8 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             if (lane == 0u) r = atomicAdd(run_ctr + region * kTicketStride, 1u);
             r = __builtin_amdgcn_readfirstlane(r) + lo;
             if (r < hi) {
-                next = r * kSegment;
-                seg_end = (n_queue - next < kSegment) ? n_queue : next + kSegment;
+                next = r * seg;
+                seg_end = (n_queue - next < seg) ? n_queue : next + seg;
                 return true;
             }
             if (++regions_tried >= kTicketRegions) return false;
@@ -428,8 +434,8 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         if (!grab()) return;
     } else {
         if (wave >= n_runs) return;
-        next = wave * kSegment;
-        seg_end = (n_queue - next < kSegment) ? n_queue : next + kSegment;
+        next = wave * seg;
+        seg_end = (n_queue - next < seg) ? n_queue : next + seg;
     }
     const GridDesc& g = w.grid;
     const HotObject* __restrict__ hot = w.rp.scene.hot;
@@ -443,6 +449,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
     float T = kMaxFloat, slack = 0.f, dd = 0.f;
     int idx = -1;
     bool cur_sphere = false;
+    bool in_lt = false;    // shadow rays of the last light: the lane's list is a light tile (no cell walk: the list is all there is)
     bool pend = false;     // a candidate that passed the pre-test and awaits the exact test
     uint32_t pend_k = 0;   // ... its object, and the object of the last exact test: an object is registered in every cell its
     uint32_t done_k = 0xffffffffu;  // sphere reaches, so a ray meets it again in the next cell(s) - once is enough
@@ -458,8 +465,12 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 if (STATS) ++s_rays;
                 pix = queue[mine];
                 ray = ANY ? load_ray(w, pix, kSlotShadow) : closest_ray(w, pix, w.first_round != 0u);
+                const uint32_t ray_light = __float_as_uint(ray.dw);  // shadow rays: the light they go to (emit_shadow)
                 ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
-                T = kMaxFloat; idx = -1; cur_sphere = false; pend = false; done_k = 0xffffffffu;
+                in_lt = false;
+                // reflection rays: the object the ray leaves has had its exact test already (begin_shade_lit)
+                if (!ANY) done_k = (w.first_round == 0u) ? ray_light : 0xffffffffu;
+                T = kMaxFloat; idx = -1; cur_sphere = false; pend = false; if (ANY) done_k = 0xffffffffu;
                 bool done = false;
                 for (uint32_t a = 0; a < g.n_always && !done; ++a) {  // objects every ray must test (usually none)
                     const int k = (int)g.always[a];
@@ -473,13 +484,27 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
                 slack = dd > 0.f ? kWalkSlackCells * g.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
                 Walk w0 = {};
-                if (!done) w0 = walk_begin(g, ray, ANY ? 1.0f + slack : 3.0e38f);
+                if (ANY && w.ltiles.enabled && ray_light == w.ltiles.light) {
+                    // the last light's shadow ray: one tile of the light's own perspective holds every object it can meet
+                    uint32_t tile;
+                    float cut;
+                    const float chk = ((ray.sx + ray.sy) + ray.sz) + ((ray.dx + ray.dy) + ray.dz);
+                    if (!done && chk == chk && light_tile_of(w.ltiles, ray.sx, ray.sy, ray.sz, tile, cut)) {
+                        slack = cut;  // (the slot is free in this mode: no cell walk) how far from the light an occluder can start
+                        const uint2 range = w.ltiles.tile_range[tile];
+                        e = range.x;
+                        e1 = range.x + range.y;
+                        if (range.y != 0u) { w0.alive = true; in_lt = true; }
+                    }
+                } else if (!done) {
+                    w0 = walk_begin(g, ray, ANY ? 1.0f + slack : 3.0e38f);
+                }
                 wk = lean_walk(g, w0);
-                if (done || !w0.alive) {  // occluded by an always-object, or the ray misses the grid box
+                if (done || !w0.alive) {  // occluded by an always-object, or the ray misses the grid box / has no light tile
                     if (ANY) U(w, F_RES_ANY, pix) = (done || nan_shadow_blocked(w.rp.scene, ray)) ? 0u : 1u;
                     else store_closest_result(w, pix, T, idx);
                 } else {
-                    st = 1;
+                    st = in_lt ? 2 : 1;
                 }
             }
             next += (uint32_t)__popcll(idle);
@@ -503,11 +528,15 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         }
         // ---- phase B: pre-test one candidate (also for a lane that has just fetched a non-empty cell) ----
         if (st == 2) {
-            const float4 bound = g.entry_sphere[e];
+            const float4 bound = (ANY && in_lt) ? w.ltiles.entry_sphere[e] : g.entry_sphere[e];
             bool pass = !misses_bounding_sphere(bound, ray, dd, g.pretest_alpha);
+            if (ANY && in_lt && w.ltiles.entry_key[e] > slack) {  // sorted by distance from the light: this entry and all after it lie beyond the ray's origin
+                pass = false;
+                e = e1 - 1u;
+            }
             uint32_t k = 0u;
             if (pass) {  // the same object again (parked, or tested a cell ago)? its result is known or on its way
-                k = g.entries[e];
+                k = (ANY && in_lt) ? w.ltiles.entries[e] : g.entries[e];
 #if RT_WALK_DEDUPE
                 if (k == done_k || (pend && k == pend_k)) pass = false;
 #endif
@@ -523,7 +552,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         // ---- step to the next cell, or end the walk ----
         if (advance) {
             const float limit = ANY ? 1.0f + slack : T + slack;
-            bool stop = !lean_next(g, wk) || wk.t_enter > limit;
+            bool stop = (ANY && in_lt) || !lean_next(g, wk) || wk.t_enter > limit;
             while (skip != 0u && !stop) {  // empty space: step on without fetching (same cells, same order, same checks)
                 --skip;
                 stop = !lean_next(g, wk) || wk.t_enter > limit;
@@ -573,11 +602,14 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 7      // <= 72 VGPRs (closest-hit variant: no spills, shadow variant: 24 B) - 24.5 vs 24.85 ms at 6
 #endif
+#ifndef RT_WAVES_PER_EU_ANY
+#define RT_WAVES_PER_EU_ANY RT_WAVES_PER_EU  // the shadow-ray variant (it also carries the light-tile path)
+#endif
 #ifndef RT_WAVES_PER_EU_TRI
 #define RT_WAVES_PER_EU_TRI 6  // the variants that know triangles would like ~90 VGPRs; 5 waves without spills measured slower (97.6 vs 93 ms, cfg5)
 #endif
 template <bool FUSED, bool ANY, bool STATS, bool TRI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRI ? RT_WAVES_PER_EU_TRI : RT_WAVES_PER_EU))) void wf_trace_grid_persistent(const WfParams wk,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRI ? RT_WAVES_PER_EU_TRI : (ANY ? RT_WAVES_PER_EU_ANY : RT_WAVES_PER_EU)))) void wf_trace_grid_persistent(const WfParams wk,
                                                                  uint32_t* __restrict__ run_ctr) {
     WfParams w = wk;
     if (!resolve_round(w)) return;
@@ -691,6 +723,7 @@ __device__ __forceinline__ void emit_shadow(Ctx& c, const HitRec& h, uint32_t li
     normalize3(vvx, vvy, vvz);
     LightGeom g;
     light_geometry<FUSED>(S.lights[li], h, nvx, nvy, nvz, vvx, vvy, vvz, g);
+    g.shadow.dw = __uint_as_float(li);  // direction.w of a shadow ray is 0 and no any-hit test reads the slot: it carries the light index to the trace kernel (light tiles)
     store_ray(c.w, c.i, g.shadow, kSlotShadow);
     if (new_hit) store_block(c.w, F_PX, c.i, make_float4(h.px, h.py, h.pz, __uint_as_float((uint32_t)h.index)));
     store_block(c.w, F_NX, c.i, make_float4(h.nx, h.ny, h.nz, __uint_as_float(phase | (li << kPhaseLightShift))));
@@ -718,6 +751,17 @@ __device__ __forceinline__ void begin_shade_lit(Ctx& c, const HitRec& h, bool pr
     if (KERNEL == 2 && !S.literal && spec_bounces > 0u && spec_ap <= 0.999f) {
         Ray ray;
         reflection_ray<FUSED>(h, ray);
+        if (c.w.grid.enabled) {
+            // The ray starts a skin's width off the object it leaves, i.e. inside that object's registration sphere: the
+            // grid walk would park it as its first candidate and spend a (sparsely filled) exact-test round on it. Its
+            // matrix is in registers here, in a kernel whose lanes all have work: run the reference's exact test against
+            // the ray's own object NOW and tell the walk (direction.w of a reflection ray is 0 and no traversal reads the
+            // slot) that this object is done. If the test ever reports a hit, nothing is said and the walk tests it as usual.
+            float t_self;
+            bool sphere_self;
+            const bool self_hit = lane_candidate<FUSED, true, true>(S.hot + h.index, ray, t_self, sphere_self);
+            ray.dw = __uint_as_float(self_hit ? 0xffffffffu : (uint32_t)h.index);
+        }
         store_ray(c.w, c.i, ray, kSlotClosest);
         c.want_closest = true;
         c.traced += 1;
@@ -867,7 +911,8 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
         int idx;
         closest_result(c.w, i, false, T, idx);
         if (T == kMaxFloat) { finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces); return; }
-        const Ray ray = load_ray(c.w, i, kSlotClosest);
+        Ray ray = load_ray(c.w, i, kSlotClosest);
+        ray.dw = 0.0f;  // (a reflection ray's direction.w; the slot may carry begin_shade_lit's note to the walk)
         HitRec rh;
         materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
         store_loop_state(c, abr, abg, abb, rr, rg, rb, ap, bounces, false);
@@ -877,6 +922,7 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
     }
     Ray ray;
     reflection_ray<FUSED>(from, ray);
+    ray.dw = __uint_as_float(0xffffffffu);  // (no note for the walk - see begin_shade_lit; no traversal reads direction.w of a reflection ray)
     store_ray(c.w, c.i, ray, kSlotClosest);
     store_loop_state(c, abr, abg, abb, rr, rg, rb, ap, bounces, true);
     U(c.w, F_PHASE, c.i) = PH_REFLECT;
@@ -950,7 +996,8 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
         if (T == kMaxFloat || !(ap <= 0.999f)) {  // raycast() false, or the absorption test of the loop condition
             finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces);
         } else {
-            const Ray ray = load_ray(w, i, kSlotClosest);
+            Ray ray = load_ray(w, i, kSlotClosest);
+            ray.dw = 0.0f;  // (a reflection ray's direction.w; the slot may carry begin_shade_lit's note to the walk)
             HitRec rh;
             materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
             begin_shade<KERNEL, FUSED>(c, rh, false, bounces, ap + (1.f - ap) * S.cold[rh.index].amb_absorb.w);
@@ -1067,7 +1114,7 @@ static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255u) / 25
 #define RT_MAX_WAVES 8192  // 256 CUs x 4 SIMDs x 8: every wave that can be resident
 #endif
 static inline dim3 persistent_grid(uint64_t n) {
-    uint64_t waves = (n + kSegment - 1) / kSegment;
+    uint64_t waves = (n + 63) / 64;  // (the kernel shortens its runs to 64 entries for small queues)
     if (waves > (uint64_t)RT_MAX_WAVES) waves = RT_MAX_WAVES;
     if (waves == 0) waves = 1;
     return dim3((uint32_t)((waves + 3u) / 4u));
@@ -1105,6 +1152,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
     w.shadow_pairs = buf.shadow_pairs;
     w.grid = buf.grid;
     w.tiles = buf.tiles;
+    w.ltiles = buf.light_tiles;
     for (int a = 0; a < 2; ++a) { w.qs[a][0] = buf.q_closest[a]; w.qs[a][1] = buf.q_any[a]; }
     uint32_t* rs = buf.counts;
     if ((e = hipMemsetAsync(rs, 0, wavefront_counter_bytes(), stream)) != hipSuccess) return e;
