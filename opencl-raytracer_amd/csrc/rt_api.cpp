@@ -808,6 +808,8 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
         if (pass == 0) {
             for (size_t k = 0; k < n_cells; ++k) start[k + 1] += start[k];
             total = start[n_cells];
+            // the kernels address these tables with 32-bit byte offsets (table_at)
+            if ((uint64_t)total * 16ull >= 0xffffffffull || (uint64_t)n_cells * 8ull >= 0xffffffffull) return RT_OK;
         } else {
             RT_HIP(c, hipMalloc((void**)&c->d_grid_entries, sizeof(uint32_t) * (total + 1)));
             RT_HIP(c, hipMalloc((void**)&c->d_grid_always, sizeof(uint32_t) * (always.size() + 1)));
@@ -983,7 +985,7 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
         if (total <= 24ull * n + 4096ull || T <= 16u) break;
         T /= 2u;
     }
-    if (total > 64ull * n + 4096ull || total > 0x7fffffffull) return RT_OK;  // objects too wide as seen from the light
+    if (total > 64ull * n + 4096ull || total * 16ull >= 0xffffffffull) return RT_OK;  // objects too wide as seen from the light / tables beyond 32-bit byte offsets
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
             for (size_t k = 0; k < (size_t)T * T; ++k) start[k + 1] += start[k];

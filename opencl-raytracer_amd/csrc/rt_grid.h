@@ -59,6 +59,14 @@ struct GridDesc {
     uint32_t enabled;
 };
 
+// Element `index` of a read-only table smaller than 4 GiB (build_grid / build_light_tiles refuse larger ones): the byte
+// offset is formed in 32 bits, so the load takes the scalar-base + 32-bit-vector-offset form instead of a 64-bit vector
+// address computed with two more vector instructions per load - the walk does three such loads per trip.
+template <typename T>
+__device__ __forceinline__ T table_at(const T* __restrict__ base, uint32_t index) {
+    return *reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (uint32_t)(index * (uint32_t)sizeof(T)));
+}
+
 // screen tiles for pinhole primary rays (built on the host per camera, rt_api.cpp: build_screen_tiles)
 struct ScreenTiles {
     const uint32_t* __restrict__ tile_start;  // tiles_x * tiles_y + 1 offsets
@@ -282,7 +290,10 @@ struct LeanWalk {
     int c;                 // current cell (linear index)
     int rx, ry, rz;        // steps left along each axis before the walk leaves the grid
     float tx, ty, tz;      // ray parameter at the next x / y / z cell wall
-    float dtx, dty, dtz;   // parameter advance per cell, carrying the SIGN of the step along that axis
+    float dtx, dty, dtz;   // parameter advance per cell (>= 0)
+    int sx, sy, sz;        // what a step along x / y / z adds to the cell index (+-1, +-nx, +-nx ny): three registers that
+                           // save three compares and three selects with scalar operands per step (the walk has them
+                           // to spare at 6 waves per SIMD; a compare or a select costs ~2x a plain vector instruction)
     float t_enter;
 };
 
@@ -293,9 +304,10 @@ __device__ __forceinline__ LeanWalk lean_walk(const GridDesc& g, const Walk& w) 
     k.ry = w.stepy > 0 ? g.ny - 1 - w.iy : w.iy;
     k.rz = w.stepz > 0 ? g.nz - 1 - w.iz : w.iz;
     k.tx = w.tx; k.ty = w.ty; k.tz = w.tz;
-    k.dtx = w.stepx > 0 ? w.dtx : -w.dtx;
-    k.dty = w.stepy > 0 ? w.dty : -w.dty;
-    k.dtz = w.stepz > 0 ? w.dtz : -w.dtz;
+    k.dtx = w.dtx; k.dty = w.dty; k.dtz = w.dtz;
+    k.sx = w.stepx > 0 ? 1 : -1;
+    k.sy = w.stepy > 0 ? g.nx : -g.nx;
+    k.sz = w.stepz > 0 ? g.nx * g.ny : -(g.nx * g.ny);
     k.t_enter = w.t_enter;
     return k;
 }
@@ -308,13 +320,10 @@ __device__ __forceinline__ bool lean_next(const GridDesc& g, LeanWalk& k) {
     const bool ay = !ax && (k.ty <= k.tz);
     const bool az = !ax && !ay;
     k.t_enter = tmin;
-    k.tx += ax ? __builtin_fabsf(k.dtx) : 0.f;
-    k.ty += ay ? __builtin_fabsf(k.dty) : 0.f;
-    k.tz += az ? __builtin_fabsf(k.dtz) : 0.f;
-    const int sx = k.dtx < 0.f ? -1 : 1;
-    const int sy = k.dty < 0.f ? -g.nx : g.nx;
-    const int sz = k.dtz < 0.f ? -(g.nx * g.ny) : g.nx * g.ny;
-    k.c += (ax ? sx : 0) + (ay ? sy : 0) + (az ? sz : 0);
+    k.tx += ax ? k.dtx : 0.f;
+    k.ty += ay ? k.dty : 0.f;
+    k.tz += az ? k.dtz : 0.f;
+    k.c += ax ? k.sx : (ay ? k.sy : k.sz);
     k.rx -= ax ? 1 : 0;
     k.ry -= ay ? 1 : 0;
     k.rz -= az ? 1 : 0;

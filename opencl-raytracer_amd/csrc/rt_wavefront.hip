@@ -491,7 +491,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                     const float chk = ((ray.sx + ray.sy) + ray.sz) + ((ray.dx + ray.dy) + ray.dz);
                     if (!done && chk == chk && light_tile_of(w.ltiles, ray.sx, ray.sy, ray.sz, tile, cut)) {
                         slack = cut;  // (the slot is free in this mode: no cell walk) how far from the light an occluder can start
-                        const uint2 range = w.ltiles.tile_range[tile];
+                        const uint2 range = table_at(w.ltiles.tile_range, tile);
                         e = range.x;
                         e1 = range.x + range.y;
                         if (range.y != 0u) { w0.alive = true; in_lt = true; }
@@ -520,7 +520,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         if (STATS) { if (lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); } if (st == 1) ++s_fetch; if (st == 2) ++s_pre; }
         // ---- phase A: fetch the current cell's list ----
         if (st == 1) {
-            const uint2 range = g.cell_range[wk.c];
+            const uint2 range = table_at(g.cell_range, (uint32_t)wk.c);
             e = range.x;
             e1 = range.x + range.y;
             if (range.y != 0u) st = 2;
@@ -528,15 +528,15 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         }
         // ---- phase B: pre-test one candidate (also for a lane that has just fetched a non-empty cell) ----
         if (st == 2) {
-            const float4 bound = (ANY && in_lt) ? w.ltiles.entry_sphere[e] : g.entry_sphere[e];
+            const float4 bound = table_at((ANY && in_lt) ? w.ltiles.entry_sphere : g.entry_sphere, e);
             bool pass = !misses_bounding_sphere(bound, ray, dd, g.pretest_alpha);
-            if (ANY && in_lt && w.ltiles.entry_key[e] > slack) {  // sorted by distance from the light: this entry and all after it lie beyond the ray's origin
+            if (ANY && in_lt && table_at(w.ltiles.entry_key, e) > slack) {  // sorted by distance from the light: this entry and all after it lie beyond the ray's origin
                 pass = false;
                 e = e1 - 1u;
             }
             uint32_t k = 0u;
             if (pass) {  // the same object again (parked, or tested a cell ago)? its result is known or on its way
-                k = (ANY && in_lt) ? w.ltiles.entries[e] : g.entries[e];
+                k = table_at((ANY && in_lt) ? w.ltiles.entries : g.entries, e);
 #if RT_WALK_DEDUPE
                 if (k == done_k || (pend && k == pend_k)) pass = false;
 #endif
@@ -600,7 +600,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
 }
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 7      // <= 72 VGPRs (closest-hit variant: no spills, shadow variant: 24 B) - 24.5 vs 24.85 ms at 6
+#define RT_WAVES_PER_EU 6      // <= 80 VGPRs, no spills (round 2: 19.75-19.8 ms per cfg4 frame vs 20.0-20.07 at 7, where the walk spills ~8 VGPRs + 30-40 SGPRs)
 #endif
 #ifndef RT_WAVES_PER_EU_ANY
 #define RT_WAVES_PER_EU_ANY RT_WAVES_PER_EU  // the shadow-ray variant (it also carries the light-tile path)

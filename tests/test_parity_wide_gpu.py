@@ -234,3 +234,38 @@ def test_device_render_is_ordered_with_the_callers_stream(n_objs):
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
     finally:
         srt.close()
+
+
+@pytest.mark.parametrize("axis,sign", [(0, 1), (0, -1), (1, 1), (1, -1), (2, 1), (2, -1)])
+def test_light_tiles_for_a_last_light_on_every_side_of_the_cloud(axis, sign, restatement):
+    """The shadow rays of the LAST light go through the light tiles (rt_grid.h) when every object lies on one side of an
+    axis-aligned plane through that light: one scene per projection axis and sign, with earlier lights inside the cloud
+    (their rays keep the grid walk), mixed spheres / boxes / anisotropic instances. Default path == brute force bit for
+    bit, == oracle within tolerance, same reference ray count."""
+    rng = np.random.default_rng(700 + 2 * axis + (sign > 0))
+    centre = np.array([0.0, 0.0, -40.0])
+    objs = []
+    for k in range(700):
+        pos = centre + rng.uniform(-12, 12, 3)
+        sc = rng.uniform(0.3, 1.2, 3) if k % 5 == 0 else np.full(3, rng.uniform(0.3, 1.2))
+        mv, inv = __import__("helpers").instance(pos, __import__("helpers").rotation(rng.normal(size=3), rng.uniform(0, 6)), sc)
+        mat = R.Material(ambient=rng.uniform(0, 1, 3), diffuse=rng.uniform(0, 1, 3), specular=rng.uniform(0, 1, 3),
+                         absorption=float(rng.choice([1.0, 0.6, 0.3])), reflection=0.0, shininess=float(rng.choice([1.0, 8.0, 40.0])))
+        objs.append(R.make_object(R.BOX if k % 7 == 0 else R.SPHERE, mat, mv, inv))
+    objs = R.objects_array(objs)
+    props = R.LightProperties((.1, .1, .1), (.5, .5, .5), (.6, .6, .6))
+    last = centre.copy()
+    last[axis] += sign * 30.0
+    lights = R.lights_array([R.make_light(props, position=(*(centre + rng.uniform(-5, 5, 3)), 1.0)),
+                             R.make_light(props, position=(*last, 1.0))])
+    rays = camera.primary_rays(96, 64)
+    want = restatement[True].render("shade_and_reflect", objs, lights, rays, 2)
+    outs = {}
+    for grid in (True, False):
+        with hip(objs, lights, rays, 2, grid=grid) as rt:
+            outs[grid] = rt.Render()
+            st = rt.count_rays()
+            assert st.wavefront == 1 and st.rays_reference == want["rays_ref"]
+    assert np.array_equal(outs[True].view(np.uint32), outs[False].view(np.uint32))
+    assert compare_frames(outs[True], want["out"]) <= RGB_ATOL
+    assert int((want["hit_index"] >= 0).sum()) > 800
