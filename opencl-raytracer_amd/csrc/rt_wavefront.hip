@@ -1113,9 +1113,21 @@ static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255u) / 25
 #ifndef RT_MAX_WAVES
 #define RT_MAX_WAVES 8192  // 256 CUs x 4 SIMDs x 8: every wave that can be resident
 #endif
-static inline dim3 persistent_grid(uint64_t n) {
+// A round's two walks run on two streams. Both are persistent: whichever gets the wave slots first keeps them until its
+// queue is empty, so launched at full size they run one after the other. The closest-hit walk is bound by instruction
+// issue, the shadow walk (light tiles: a few dependent loads per ray) by memory latency - given a share of the slots
+// each, the second might hide in the first. MEASURED (cfg4 frame, closest / shadow wave caps): 8192 / 8192 (launched at full
+// size, in effect one after the other) 19.6 ms; 6144 / 2048 20.15; 5120 / 2048 20.2; 5120 / 1024 20.8; 4096 / 2048 21.7 -
+// the closest-hit walk needs every slot it can get, the knobs stay at "full size".
+#ifndef RT_MAX_WAVES_CLOSEST_SHARED
+#define RT_MAX_WAVES_CLOSEST_SHARED RT_MAX_WAVES
+#endif
+#ifndef RT_MAX_WAVES_ANY_SHARED
+#define RT_MAX_WAVES_ANY_SHARED RT_MAX_WAVES
+#endif
+static inline dim3 persistent_grid(uint64_t n, uint64_t max_waves) {
     uint64_t waves = (n + 63) / 64;  // (the kernel shortens its runs to 64 entries for small queues)
-    if (waves > (uint64_t)RT_MAX_WAVES) waves = RT_MAX_WAVES;
+    if (waves > max_waves) waves = max_waves;
     if (waves == 0) waves = 1;
     return dim3((uint32_t)((waves + 3u) / 4u));
 }
@@ -1127,8 +1139,8 @@ size_t wavefront_counter_bytes() { return sizeof(uint32_t) * (size_t)(kTicketBas
 // one launch of the persistent grid walk (the template arguments pick the compiled variant); `n_max` = the most the
 // queue can hold, the kernel reads its real length from the round state
 template <bool FUSED, bool ANY>
-static void launch_persistent(const WfParams& w, uint64_t n_max, uint32_t* ticket, hipStream_t s) {
-    const dim3 grid = persistent_grid(n_max), block(256);
+static void launch_persistent(const WfParams& w, uint64_t n_max, uint32_t* ticket, hipStream_t s, bool shared) {
+    const dim3 grid = persistent_grid(n_max, shared ? (ANY ? RT_MAX_WAVES_ANY_SHARED : RT_MAX_WAVES_CLOSEST_SHARED) : RT_MAX_WAVES), block(256);
     const bool tri = w.grid.has_triangles != 0u;
     if (w.count_rays) {
         if (tri) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, true, true>), grid, block, 0, s, w, ticket);
@@ -1179,7 +1191,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
             any_stream = buf.side_stream;
             if ((e2 = hipEventRecord(buf.ev_fork, stream)) != hipSuccess) return e2;
             if ((e2 = hipStreamWaitEvent(any_stream, buf.ev_fork, 0)) != hipSuccess) return e2;
-            launch_persistent<FUSED, true>(w, na_max, rs + kTicketBase + kTicketWords, any_stream);
+            launch_persistent<FUSED, true>(w, na_max, rs + kTicketBase + kTicketWords, any_stream, true);
             if ((e2 = hipGetLastError()) != hipSuccess) return e2;
             if ((e2 = hipEventRecord(buf.ev_join, any_stream)) != hipSuccess) return e2;
         }
@@ -1187,7 +1199,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
             if (use_grid && first && w.tiles.enabled && w.rp.pinhole) {
                 hipLaunchKernelGGL((wf_trace_primary_tiles<FUSED>), grid_for(nc_max), dim3(256), 0, stream, w);
             } else if (use_grid) {
-                launch_persistent<FUSED, false>(w, nc_max, rs + kTicketBase, stream);  // (a grid implies direction.w = 0)
+                launch_persistent<FUSED, false>(w, nc_max, rs + kTicketBase, stream, side_by_side);  // (a grid implies direction.w = 0)
             } else {
                 if (first && !w.rp.dir_w_zero) hipLaunchKernelGGL((wf_trace_closest<FUSED, false>), grid_for(nc_max), dim3(256), 0, stream, w);
                 else hipLaunchKernelGGL((wf_trace_closest<FUSED, true>), grid_for(nc_max), dim3(256), 0, stream, w);
@@ -1201,7 +1213,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
                 hipLaunchKernelGGL((wf_trace_any_literal<FUSED>), grid_for(na_max), dim3(256), 0, stream, w);
                 if ((e2 = hipGetLastError()) != hipSuccess) return e2;
             } else if (use_grid) {
-                launch_persistent<FUSED, true>(w, na_max, rs + kTicketBase + kTicketWords, stream);
+                launch_persistent<FUSED, true>(w, na_max, rs + kTicketBase + kTicketWords, stream, false);
                 if ((e2 = hipGetLastError()) != hipSuccess) return e2;
             } else {
                 // slices of >= kMinSlicePairs pairs (amortises each launch's pipeline fill), at most kMaxSlices; the
