@@ -72,9 +72,7 @@ struct rt_context {
     std::vector<double> h_grid_spheres;     // per object: centre + grid radius (inf: always tested, < 0: never hit)
     std::vector<float> h_grid_pre;          // per object: pre-test radius as the grid's entry spheres carry it
     uint2* d_lt_range = nullptr;            // light tiles (rt_grid.h: LightTiles) for the last light's shadow rays
-    uint32_t* d_lt_entries = nullptr;
-    float4* d_lt_sphere = nullptr;
-    float* d_lt_key = nullptr;
+    float4* d_lt_records = nullptr;
     rt::LightTiles light_tiles = {};
     uint32_t* d_tile_start = nullptr;       // screen tiles (64 x 8 pixels) -> objects a pinhole primary ray can reach
     uint32_t* d_tile_entries = nullptr;
@@ -985,7 +983,7 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
         if (total <= 24ull * n + 4096ull || T <= 16u) break;
         T /= 2u;
     }
-    if (total > 64ull * n + 4096ull || total * 16ull >= 0xffffffffull) return RT_OK;  // objects too wide as seen from the light / tables beyond 32-bit byte offsets
+    if (total > 64ull * n + 4096ull || total * 32ull >= 0xffffffffull) return RT_OK;  // objects too wide as seen from the light / table beyond 32-bit byte offsets
     for (int pass = 0; pass < 2; ++pass) {
         if (pass == 1) {
             for (size_t k = 0; k < (size_t)T * T; ++k) start[k + 1] += start[k];
@@ -1018,28 +1016,21 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
     }
     for (size_t t = 0; t < ranges.size(); ++t)
         std::sort(entries.begin() + start[t], entries.begin() + start[t + 1], [&](uint32_t a, uint32_t b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
-    std::vector<float4> es((size_t)total);
-    std::vector<float> ek((size_t)total);
+    std::vector<float4> recs(2 * (size_t)total);
     for (size_t k = 0; k < (size_t)total; ++k) {
         const uint32_t i = entries[k];
-        es[k] = make_float4((float)c->h_grid_spheres[4 * i], (float)c->h_grid_spheres[4 * i + 1], (float)c->h_grid_spheres[4 * i + 2], c->h_grid_pre[i]);
-        ek[k] = key[i];
+        float id_bits;
+        std::memcpy(&id_bits, &i, 4);
+        recs[2 * k] = make_float4((float)c->h_grid_spheres[4 * i], (float)c->h_grid_spheres[4 * i + 1], (float)c->h_grid_spheres[4 * i + 2], c->h_grid_pre[i]);
+        recs[2 * k + 1] = make_float4(key[i], id_bits, 0.f, 0.f);
     }
-    RT_HIP(c, hipMalloc((void**)&c->d_lt_key, sizeof(float) * ((size_t)total + 1)));
-    if (total) RT_HIP(c, hipMemcpy(c->d_lt_key, ek.data(), sizeof(float) * (size_t)total, hipMemcpyHostToDevice));
     RT_HIP(c, hipMalloc((void**)&c->d_lt_range, sizeof(uint2) * ranges.size()));
-    RT_HIP(c, hipMalloc((void**)&c->d_lt_entries, sizeof(uint32_t) * ((size_t)total + 1)));
-    RT_HIP(c, hipMalloc((void**)&c->d_lt_sphere, sizeof(float4) * ((size_t)total + 1)));
+    RT_HIP(c, hipMalloc((void**)&c->d_lt_records, sizeof(float4) * (recs.size() + 2)));
     RT_HIP(c, hipMemcpy(c->d_lt_range, ranges.data(), sizeof(uint2) * ranges.size(), hipMemcpyHostToDevice));
-    if (total) {
-        RT_HIP(c, hipMemcpy(c->d_lt_entries, entries.data(), sizeof(uint32_t) * (size_t)total, hipMemcpyHostToDevice));
-        RT_HIP(c, hipMemcpy(c->d_lt_sphere, es.data(), sizeof(float4) * (size_t)total, hipMemcpyHostToDevice));
-    }
+    if (total) RT_HIP(c, hipMemcpy(c->d_lt_records, recs.data(), sizeof(float4) * recs.size(), hipMemcpyHostToDevice));
     rt::LightTiles& lt = c->light_tiles;
     lt.tile_range = c->d_lt_range;
-    lt.entries = c->d_lt_entries;
-    lt.entry_sphere = c->d_lt_sphere;
-    lt.entry_key = c->d_lt_key;
+    lt.records = c->d_lt_records;
     lt.lx = lp[0]; lt.ly = lp[1]; lt.lz = lp[2];
     lt.u0 = u0f; lt.v0 = v0f; lt.inv_du = inv_du; lt.inv_dv = inv_dv;
     lt.tiles_u = T; lt.tiles_v = T;
@@ -1387,9 +1378,7 @@ void rt_destroy(rt_context* c) {
     if (c->d_tile_start) (void)hipFree(c->d_tile_start);
     if (c->d_tile_entries) (void)hipFree(c->d_tile_entries);
     if (c->d_lt_range) (void)hipFree(c->d_lt_range);
-    if (c->d_lt_entries) (void)hipFree(c->d_lt_entries);
-    if (c->d_lt_sphere) (void)hipFree(c->d_lt_sphere);
-    if (c->d_lt_key) (void)hipFree(c->d_lt_key);
+    if (c->d_lt_records) (void)hipFree(c->d_lt_records);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->d_out) (void)hipFree(c->d_out);

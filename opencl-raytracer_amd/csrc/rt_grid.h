@@ -85,10 +85,11 @@ struct ScreenTiles {
 // candidate still goes through the pre-test and the reference's exact test, so the answer is the brute-force loop's.
 struct LightTiles {
     const uint2* __restrict__ tile_range;      // tiles_u * tiles_v x {first entry, count}
-    const uint32_t* __restrict__ entries;      // object indices
-    const float4* __restrict__ entry_sphere;   // parallel: centre (view space) + pre-test radius, as GridDesc::entry_sphere
-    const float* __restrict__ entry_key;       // parallel: distance from the light to the nearest point of the registration sphere;
-                                               // a tile's entries are sorted by it, and a ray's list ENDS at the first key beyond its origin
+    const float4* __restrict__ records;        // two float4 per entry, side by side (one or two cache lines per ray instead of three tables):
+                                               //   [0] centre (view space) + pre-test radius, as GridDesc::entry_sphere
+                                               //   [1].x distance from the light to the nearest point of the registration sphere - a tile's entries
+                                               //        are sorted by it, and a ray's list ENDS at the first key beyond its own origin;
+                                               //   [1].y object index (bits)
     float lx, ly, lz;                          // the light
     float u0, v0, inv_du, inv_dv;              // tile (iu, iv) covers u0 + iu / inv_du ...
     uint32_t tiles_u, tiles_v;

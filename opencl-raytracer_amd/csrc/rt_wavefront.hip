@@ -177,6 +177,8 @@ __device__ __forceinline__ void push(uint32_t* queue, uint32_t* counter, uint64_
 #define RT_RESUME_THREADS 1024
 #endif
 constexpr int kResumeThreads = RT_RESUME_THREADS;
+constexpr uint32_t kQueueAlsoShadow = 0x80000000u;  // flag on a closest-queue entry (pixel ids are < 2^31: launch_wavefront checks)
+constexpr uint32_t kQueuePixel = 0x7fffffffu;
 __device__ __forceinline__ void block_push(bool want_closest, bool want_any, uint32_t id, uint32_t* __restrict__ q_closest,
                                            uint32_t* __restrict__ q_any, uint32_t* __restrict__ counts) {
     __shared__ uint32_t s_cnt[2][kResumeThreads / 64];
@@ -193,7 +195,9 @@ __device__ __forceinline__ void block_push(bool want_closest, bool want_any, uin
     }
     __syncthreads();
     const unsigned long long below = (1ull << lane) - 1ull;
-    if (want_closest) q_closest[s_base[0] + s_cnt[0][wave] + (uint32_t)__popcll(bc & below)] = id;
+    // a pixel that queues a shadow ray AND a reflection ray sits in both queues and is resumed from its shadow entry: its
+    // closest-queue entry says so in its top bit, so that wf_resume can drop it without touching the pixel's state
+    if (want_closest) q_closest[s_base[0] + s_cnt[0][wave] + (uint32_t)__popcll(bc & below)] = want_any ? (id | kQueueAlsoShadow) : id;
     if (want_any) q_any[s_base[1] + s_cnt[1][wave] + (uint32_t)__popcll(ba & below)] = id;
 }
 
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(256) void wf_trace_closest(const WfParams wk) {
     if (!resolve_round(w)) return;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= w.n_prev_closest) return;
-    const uint64_t i = w.q_prev_closest[t];
+    const uint64_t i = w.q_prev_closest[t] & kQueuePixel;
     const Ray ray = closest_ray(w, i, w.first_round != 0u);
     float T = kMaxFloat;
     int idx = -1;
@@ -307,7 +311,7 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams wk)
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= w.n_prev_closest) return;
     const RenderParams& p = w.rp;
-    const uint64_t i = w.q_prev_closest[t];
+    const uint64_t i = w.q_prev_closest[t] & kQueuePixel;
     const uint64_t g = global_ray_of(p, i);
     const Ray ray = primary_ray(p, g);
     const uint32_t row = (uint32_t)g / p.width, col = (uint32_t)g - row * p.width;
@@ -463,7 +467,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             if (STATS && lane == 0u) ++s_refill;
             if (st == 0 && mine < seg_end) {
                 if (STATS) ++s_rays;
-                pix = queue[mine];
+                pix = queue[mine] & kQueuePixel;
                 ray = ANY ? load_ray(w, pix, kSlotShadow) : closest_ray(w, pix, w.first_round != 0u);
                 const uint32_t ray_light = __float_as_uint(ray.dw);  // shadow rays: the light they go to (emit_shadow)
                 ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
@@ -528,15 +532,17 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         }
         // ---- phase B: pre-test one candidate (also for a lane that has just fetched a non-empty cell) ----
         if (st == 2) {
-            const float4 bound = table_at((ANY && in_lt) ? w.ltiles.entry_sphere : g.entry_sphere, e);
+            float4 bound, aux = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ANY && in_lt) { bound = table_at(w.ltiles.records, 2u * e); aux = table_at(w.ltiles.records, 2u * e + 1u); }
+            else bound = table_at(g.entry_sphere, e);
             bool pass = !misses_bounding_sphere(bound, ray, dd, g.pretest_alpha);
-            if (ANY && in_lt && table_at(w.ltiles.entry_key, e) > slack) {  // sorted by distance from the light: this entry and all after it lie beyond the ray's origin
+            if (ANY && in_lt && aux.x > slack) {  // sorted by distance from the light: this entry and all after it lie beyond the ray's origin
                 pass = false;
                 e = e1 - 1u;
             }
             uint32_t k = 0u;
             if (pass) {  // the same object again (parked, or tested a cell ago)? its result is known or on its way
-                k = table_at((ANY && in_lt) ? w.ltiles.entries : g.entries, e);
+                k = (ANY && in_lt) ? __float_as_uint(aux.y) : table_at(g.entries, e);
 #if RT_WALK_DEDUPE
                 if (k == done_k || (pend && k == pend_k)) pass = false;
 #endif
@@ -1006,9 +1012,8 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
 }
 
 // a pixel with a shadow AND a reflection ray in flight sits in both queues: it is resumed from its shadow entry
-__device__ __forceinline__ bool duplicate_entry(const WfParams& w, uint32_t t, uint64_t i) {
-    const uint32_t phase = U(w, F_PHASE, i) & 0xffu;
-    return (t < w.n_prev_closest) && (phase == PH_SHADOW_PRIMARY || phase == PH_SHADOW_REFLECT);
+__device__ __forceinline__ bool duplicate_entry(const WfParams& w, uint32_t t, uint32_t entry) {
+    return (t < w.n_prev_closest) && (entry & kQueueAlsoShadow) != 0u;
 }
 
 __device__ __forceinline__ void add_ray_counters(const WfParams& w, const Ctx& c) {
@@ -1032,8 +1037,9 @@ __global__ __launch_bounds__(kResumeThreads) __attribute__((amdgpu_waves_per_eu(
     const uint32_t total = w.n_prev_closest + w.n_prev_any;
     Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u, 0u, make_float4(0.f, 0.f, 0.f, 0.f)};
     if (t < total) {
-        c.i = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
-        if (!duplicate_entry(w, t, c.i)) resume_pixel<KERNEL, FUSED>(c);
+        const uint32_t entry = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
+        c.i = entry & kQueuePixel;
+        if (!duplicate_entry(w, t, entry)) resume_pixel<KERNEL, FUSED>(c);
     }
     block_push(c.want_closest, c.want_any, (uint32_t)c.i, w.q_closest, w.q_any, w.counts);
     if (w.count_rays) add_ray_counters(w, c);
@@ -1054,8 +1060,9 @@ __global__ __launch_bounds__(256) void wf_finish(const WfParams wk) {
     Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u, 0u, make_float4(0.f, 0.f, 0.f, 0.f)};
     uint32_t tested = 0;
     if (t < total) {
-        c.i = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
-        if (!duplicate_entry(w, t, c.i)) {
+        const uint32_t entry = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
+        c.i = entry & kQueuePixel;
+        if (!duplicate_entry(w, t, entry)) {
             // the queues hold rays that have NOT been traced yet: trace first, then resume, and so on to the end
             bool do_closest = (t < w.n_prev_closest) || (U(w, F_PHASE, c.i) & PH_FLAG_REFLECTION_PENDING) != 0u;
             bool do_any = !(t < w.n_prev_closest);
@@ -1279,6 +1286,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
 
 hipError_t launch_wavefront(const RenderParams& p, int kernel, bool fused, bool count, WavefrontBuffers& buf,
                             hipStream_t stream, uint32_t* rounds_out) {
+    if (p.n_local >= 0x7fffffffull) return hipErrorInvalidValue;  // queue entries are pixel ids in 31 bits + a flag
     WfParams w;
     std::memset(&w, 0, sizeof(w));
     w.rp = p;
