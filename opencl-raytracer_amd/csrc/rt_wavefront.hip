@@ -86,6 +86,8 @@ struct WfParams {
     uint32_t n_prev_closest, n_prev_any;
     int kernel;
     uint32_t first_round;  // the closest-hit rays of this round are the primary rays (never stored: closest_ray())
+    uint32_t identity_queue;  // ... and its queue is implicit: entry t is work-item t, every work-item is in phase PH_PRIMARY
+                              // (no wf_begin, no queue to write and read back, no phase words - frames without padding work-items)
     uint32_t count_rays;  // instrumentation on
 };
 
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256) void wf_trace_closest(const WfParams wk) {
     if (!resolve_round(w)) return;
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= w.n_prev_closest) return;
-    const uint64_t i = w.q_prev_closest[t] & kQueuePixel;
+    const uint64_t i = w.identity_queue ? t : (w.q_prev_closest[t] & kQueuePixel);
     const Ray ray = closest_ray(w, i, w.first_round != 0u);
     float T = kMaxFloat;
     int idx = -1;
@@ -311,7 +313,7 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams wk)
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= w.n_prev_closest) return;
     const RenderParams& p = w.rp;
-    const uint64_t i = w.q_prev_closest[t] & kQueuePixel;
+    const uint64_t i = w.identity_queue ? t : (w.q_prev_closest[t] & kQueuePixel);
     const uint64_t g = global_ray_of(p, i);
     const Ray ray = primary_ray(p, g);
     const uint32_t row = (uint32_t)g / p.width, col = (uint32_t)g - row * p.width;
@@ -467,7 +469,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             if (STATS && lane == 0u) ++s_refill;
             if (st == 0 && mine < seg_end) {
                 if (STATS) ++s_rays;
-                pix = queue[mine] & kQueuePixel;
+                pix = (!ANY && w.identity_queue) ? mine : (queue[mine] & kQueuePixel);
                 ray = ANY ? load_ray(w, pix, kSlotShadow) : closest_ray(w, pix, w.first_round != 0u);
                 const uint32_t ray_light = __float_as_uint(ray.dw);  // shadow rays: the light they go to (emit_shadow)
                 ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
@@ -962,7 +964,7 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
     const WfParams& w = c.w;
     const uint64_t i = c.i;
     const Scene& S = w.rp.scene;
-    c.nblock = load_block(w, F_NX, i);
+    c.nblock = w.identity_queue ? make_float4(0.f, 0.f, 0.f, __uint_as_float(PH_PRIMARY)) : load_block(w, F_NX, i);
     const uint32_t word = __float_as_uint(c.nblock.w);
     const uint32_t phase = word & 0xffu;
     c.flags = word & (PH_FLAG_REFLECTION_SENT | PH_FLAG_REFLECTION_PENDING);
@@ -1037,7 +1039,7 @@ __global__ __launch_bounds__(kResumeThreads) __attribute__((amdgpu_waves_per_eu(
     const uint32_t total = w.n_prev_closest + w.n_prev_any;
     Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u, 0u, make_float4(0.f, 0.f, 0.f, 0.f)};
     if (t < total) {
-        const uint32_t entry = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
+        const uint32_t entry = w.identity_queue ? t : ((t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest]);
         c.i = entry & kQueuePixel;
         if (!duplicate_entry(w, t, entry)) resume_pixel<KERNEL, FUSED>(c);
     }
@@ -1114,6 +1116,13 @@ __global__ __launch_bounds__(256) void wf_advance(uint32_t* __restrict__ rs, uin
     else rs[RS_ROUNDS] += 1u;
 }
 
+// First round of a frame without padding work-items: the queue is the identity (WfParams::identity_queue), only its length
+// has to be put down.
+__global__ void wf_identity_round(uint32_t* __restrict__ rs, uint32_t n) {
+    rs[RS_N_CLOSEST] = n;
+    rs[RS_ROUNDS] = 1u;
+}
+
 // ---- host driver -----------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255u) / 256u)); }
 // one wave per kSegment queue entries, four waves per workgroup
@@ -1180,15 +1189,26 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
     if (const char* env = std::getenv("RT_WF_FINISH_THRESHOLD")) finish_threshold = (uint64_t)std::atoll(env);
     if (finish_threshold > 0xffffffffull) finish_threshold = 0xffffffffull;
     const bool use_grid = w.grid.enabled && !w.rp.scene.literal;
-    hipLaunchKernelGGL(wf_begin, dim3((uint32_t)((n + kResumeThreads - 1) / kResumeThreads)), dim3(kResumeThreads), 0, stream, w);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
-    hipLaunchKernelGGL(wf_advance, dim3(1), dim3(256), 0, stream, rs, (uint32_t)finish_threshold, 0u);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // padding work-items exist only in the ragged last tile of a sharded frame: they must not be traced (their global ray
+    // does not exist), so such frames go through wf_begin, which leaves them out of the first queue
+    const bool padded = w.rp.world > 1u && (n % w.rp.tile_rays != 0u || ((n / w.rp.tile_rays - 1u) * w.rp.world + w.rp.rank + 1u) * w.rp.tile_rays > w.rp.n_rays);
+    static const bool always_begin = std::getenv("RT_WF_ALWAYS_BEGIN") != nullptr;  // measurement knob
+    const bool identity = !padded && !always_begin && n > 0;
+    if (identity) {
+        hipLaunchKernelGGL(wf_identity_round, dim3(1), dim3(1), 0, stream, rs, (uint32_t)n);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    } else {
+        hipLaunchKernelGGL(wf_begin, dim3((uint32_t)((n + kResumeThreads - 1) / kResumeThreads)), dim3(kResumeThreads), 0, stream, w);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(wf_advance, dim3(1), dim3(256), 0, stream, rs, (uint32_t)finish_threshold, 0u);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
 
     static const bool one_stream = std::getenv("RT_WF_ONE_STREAM") != nullptr;  // measurement knob
     auto enqueue_round = [&](bool first, uint64_t nc_max, uint64_t na_max) -> hipError_t {
         hipError_t e2;
         w.first_round = first ? 1u : 0u;
+        w.identity_queue = (first && identity) ? 1u : 0u;
         // The two launches of a round are independent (different rays, different result words): through the grid they
         // run side by side on two streams, so that each fills the other's tail and a small light-scan queue hides
         // behind a big reflection queue.

@@ -18,6 +18,7 @@ echo "bench done"
 cp $(ls $F/default_trace/*kernel_stats.csv | head -1) $F/default_bench_kernel_stats.csv
 rm -rf $F/default_trace
 echo "trace done"
+./tools/ubench/issue_forms > $F/issue_forms.txt 2>&1 || true
 python3 tools/ab/share_time.py 16 > $F/share_rehearsal.json 2> /dev/null
 RT_WALK_STATS=1 python3 bench.py --no-cpu-baseline --no-extra --steps 1 --warmup 0 2> $F/walk_stats_raw.txt > /dev/null; grep walk $F/walk_stats_raw.txt > $F/walk_stats.txt; rm -f $F/walk_stats_raw.txt
 for w in cfg2 cfg3 cfg5base cfg5; do python3 bench.py --workload $w --no-cpu-baseline > $F/bench_$w.json 2> $F/bench_$w.err; echo "$w done"; done
