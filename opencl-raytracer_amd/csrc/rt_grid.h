@@ -350,17 +350,19 @@ __device__ __forceinline__ void closest_hit_grid(const GridDesc& g, const HotObj
     if (!w.alive) return;
     // two more cells after the best hit's cell (the candidate's own t is exact; the slack covers objects that
     // start in the next cells but whose computed t the reference may place marginally earlier)
-    const float len = __builtin_sqrtf(ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz);
+    const float dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
+    const float len = __builtin_sqrtf(dd);
     const float slack = len > 0.f ? kWalkSlackCells * g.cell / len : 3.0e38f;
     for (;;) {
         const uint32_t c = ((uint32_t)w.iz * (uint32_t)g.ny + (uint32_t)w.iy) * (uint32_t)g.nx + (uint32_t)w.ix;
         const uint2 range = g.cell_range[c];
         const uint32_t e0 = range.x, e1 = range.y ? range.x + range.y : range.x;
-        tested += e1 - e0;
         for (uint32_t e = e0; e < e1; ++e) {
+            if (DW0 && misses_bounding_sphere(g.entry_sphere[e], ray, dd, g.pretest_alpha)) continue;  // the walk kernels' 16-byte pre-test (conservative)
             const int k = (int)g.entries[e];
             float t;
             bool sphere;
+            ++tested;
             if (lane_candidate<FUSED, DW0>(hot + k, ray, t, sphere)) closest_take(t, k, sphere, T, index, cur_sphere);
         }
         if (!walk_next(g, w)) break;
@@ -379,17 +381,19 @@ __device__ __forceinline__ bool any_hit_grid(const GridDesc& g, const Scene& S, 
         ++tested;
         if (lane_candidate<FUSED, true>(hot + (int)g.always[a], ray, t, sphere) && !(t >= 1.f)) return true;
     }
-    const float len = __builtin_sqrtf(ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz);
+    const float dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
+    const float len = __builtin_sqrtf(dd);
     const float slack = len > 0.f ? kWalkSlackCells * g.cell / len : 3.0e38f;
     Walk w = walk_begin(g, ray, 1.0f + slack);
     if (!w.alive) return nan_shadow_blocked(S, ray);  // off the grid: nothing in the way - unless the ray is a NaN ray
     for (;;) {
         const uint32_t c = ((uint32_t)w.iz * (uint32_t)g.ny + (uint32_t)w.iy) * (uint32_t)g.nx + (uint32_t)w.ix;
         const uint2 range = g.cell_range[c];
-        tested += range.y;
         for (uint32_t e = range.x; e < range.x + range.y; ++e) {
+            if (misses_bounding_sphere(g.entry_sphere[e], ray, dd, g.pretest_alpha)) continue;
             float t;
             bool sphere;
+            ++tested;
             if (lane_candidate<FUSED, true>(hot + (int)g.entries[e], ray, t, sphere) && !(t >= 1.f)) return true;
         }
         if (!walk_next(g, w)) break;
