@@ -694,6 +694,14 @@ __global__ __launch_bounds__(256) void wf_trace_any_slice(const WfParams wk, con
 // tests is a comparison that NaN fails. In practice these are reflections off a box hit whose object-space point
 // has no coordinate beyond 0.4998 (tiny far boxes: 0/0 normal). The brute-force kernels reproduce that by
 // construction; for the grid path it is patched in here, where the result is consumed.
+__device__ __forceinline__ void patch_nan_result(const WfParams& w, const Ray& ray, float& T, int& idx) {
+    if (T == kMaxFloat && w.grid.enabled && !w.rp.scene.literal && w.rp.scene.nan_winner >= 0) {
+        if (nan_ray_outcome(ray, w.rp.scene.nan_winner, w.rp.scene.nan_winner_sphere) == kNanRayTimeNaN) {
+            T = __builtin_nanf("");
+            idx = w.rp.scene.nan_winner;
+        }
+    }
+}
 __device__ __forceinline__ void closest_result(const WfParams& w, uint64_t i, bool primary, float& T, int& idx) {
     load_closest_result(w, i, T, idx);
     if (T == kMaxFloat && w.grid.enabled && !w.rp.scene.literal && w.rp.scene.nan_winner >= 0) {
@@ -713,6 +721,13 @@ struct Ctx {
     uint32_t flags;               // PH_FLAG_* bits of the pixel's phase word
     uint32_t li;                  // ... and its light index
     float4 nblock;                // the block the phase word came in: normal of the hit being shaded
+    // Shadow phases: everything the step will read from the pixel's own state, requested in ONE go at the top of the
+    // step (resume_pixel) instead of where each piece is used - the step is a chain of dependent memory waits (queue
+    // entry -> phase word -> hit -> material -> accumulators -> trace result -> ray -> next hit's records) at 4 waves
+    // per SIMD, and these five requests depend on the pixel index only.
+    bool pre;
+    float4 pre_hit, pre_res, pre_acc;
+    Ray pre_ray0;
 };
 
 template <int KERNEL>
@@ -796,7 +811,7 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
     const uint64_t i = c.i;
     HitRec h;
     {   // point + object, normal (came in with the phase word), and - where it is kept - the reflection vector
-        const float4 a = load_block(c.w, F_PX, i);
+        const float4 a = c.pre ? c.pre_hit : load_block(c.w, F_PX, i);
         h.px = a.x; h.py = a.y; h.pz = a.z; h.index = (int)__float_as_uint(a.w);
         h.nx = c.nblock.x; h.ny = c.nblock.y; h.nz = c.nblock.z;
         h.rx = h.ry = h.rz = 0.f;
@@ -804,7 +819,7 @@ __device__ __forceinline__ void resume_shadow(Ctx& c, bool primary) {
         if (!(KERNEL == 2 && !S.literal)) { const float4 r = load_block(c.w, F_RX, i); h.rx = r.x; h.ry = r.y; h.rz = r.z; h.pw = r.w; }
     }
     const uint32_t li = c.li;
-    const bool lit = U(c.w, F_RES_ANY, i) != 0u;
+    const bool lit = (c.pre ? __float_as_uint(c.pre_res.z) : U(c.w, F_RES_ANY, i)) != 0u;
     const ColdObject* co = S.cold + h.index;
     const float4 amb = co->amb_absorb, dif = co->dif_shine, spec = co->spec_type;
     float nvx = h.nx, nvy = h.ny, nvz = h.nz;
@@ -917,9 +932,17 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
         const uint64_t i = c.i;
         float T;
         int idx;
-        closest_result(c.w, i, false, T, idx);
+        Ray ray;
+        if (c.pre) {
+            T = c.pre_res.x;
+            idx = (int)__float_as_uint(c.pre_res.y);
+            ray = c.pre_ray0;
+            patch_nan_result(c.w, ray, T, idx);
+        } else {
+            closest_result(c.w, i, false, T, idx);
+        }
         if (T == kMaxFloat) { finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces); return; }
-        Ray ray = load_ray(c.w, i, kSlotClosest);
+        if (!c.pre) ray = load_ray(c.w, i, kSlotClosest);
         ray.dw = 0.0f;  // (a reflection ray's direction.w; the slot may carry begin_shade_lit's note to the walk)
         HitRec rh;
         materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
@@ -948,13 +971,13 @@ __device__ void shade_done(Ctx& c, const HitRec& h, bool primary, float cr, floa
         const float ap = S.cold[h.index].amb_absorb.w;
         loop_step<FUSED>(c, h, cr * ap, cg * ap, cb * ap, 0.f, 0.f, 0.f, ap, c.w.rp.max_bounces);
     } else {
-        const float4 acc = load_block(c.w, F_ABR, i);
+        const float4 acc = c.pre ? c.pre_acc : load_block(c.w, F_ABR, i);
         float ap = acc.w;
         float abr = acc.x, abg = acc.y, abb = acc.z;
         const float ra = (1.f - ap) * S.cold[h.index].amb_absorb.w;
         abr = fma_<FUSED>(ra, cr, abr); abg = fma_<FUSED>(ra, cg, abg); abb = fma_<FUSED>(ra, cb, abb);
         ap = ap + ra;
-        loop_step<FUSED>(c, h, abr, abg, abb, cr, cg, cb, ap, U(c.w, F_BOUNCES, i));
+        loop_step<FUSED>(c, h, abr, abg, abb, cr, cg, cb, ap, c.pre ? __float_as_uint(c.pre_res.w) : U(c.w, F_BOUNCES, i));
     }
 }
 
@@ -964,6 +987,7 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
     const WfParams& w = c.w;
     const uint64_t i = c.i;
     const Scene& S = w.rp.scene;
+    c.pre = false;
     c.nblock = w.identity_queue ? make_float4(0.f, 0.f, 0.f, __uint_as_float(PH_PRIMARY)) : load_block(w, F_NX, i);
     const uint32_t word = __float_as_uint(c.nblock.w);
     const uint32_t phase = word & 0xffu;
@@ -988,10 +1012,13 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
             materialise<FUSED>(S.hot, S.cold, idx, T, ray, h);
             begin_shade<KERNEL, FUSED>(c, h, true, w.rp.max_bounces, S.cold[h.index].amb_absorb.w);
         }
-    } else if (phase == PH_SHADOW_PRIMARY) {
-        resume_shadow<KERNEL, FUSED>(c, true);
-    } else if (phase == PH_SHADOW_REFLECT) {
-        resume_shadow<KERNEL, FUSED>(c, false);
+    } else if (phase == PH_SHADOW_PRIMARY || phase == PH_SHADOW_REFLECT) {
+        c.pre = true;
+        c.pre_hit = load_block(w, F_PX, i);
+        c.pre_res = load_block(w, F_RES_T, i);
+        c.pre_acc = load_block(w, F_ABR, i);       // (not yet written in the primary phase: not read there either)
+        c.pre_ray0 = load_ray(w, i, kSlotClosest);  // (only meaningful when a reflection ray left with the hit)
+        resume_shadow<KERNEL, FUSED>(c, phase == PH_SHADOW_PRIMARY);
     } else if (phase == PH_REFLECT) {
         float T;
         int idx;
@@ -1037,7 +1064,7 @@ __global__ __launch_bounds__(kResumeThreads) __attribute__((amdgpu_waves_per_eu(
     if (blockIdx.x * kResumeThreads >= w.n_prev_closest + w.n_prev_any) return;  // the grid is sized for the most the queues can hold
     const uint32_t t = blockIdx.x * kResumeThreads + threadIdx.x;
     const uint32_t total = w.n_prev_closest + w.n_prev_any;
-    Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u, 0u, make_float4(0.f, 0.f, 0.f, 0.f)};
+    Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u, 0u, make_float4(0.f, 0.f, 0.f, 0.f), false, {}, {}, {}, {}};
     if (t < total) {
         const uint32_t entry = w.identity_queue ? t : ((t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest]);
         c.i = entry & kQueuePixel;
@@ -1059,7 +1086,7 @@ __global__ __launch_bounds__(256) void wf_finish(const WfParams wk) {
     if (w.counts[RS_FINISH] != 1u) return;  // only once wf_advance has handed the rest of the frame over
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     const uint32_t total = w.n_prev_closest + w.n_prev_any;
-    Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u, 0u, make_float4(0.f, 0.f, 0.f, 0.f)};
+    Ctx c{w, 0, 0ull, 0ull, 0ull, false, false, 0u, 0u, make_float4(0.f, 0.f, 0.f, 0.f), false, {}, {}, {}, {}};
     uint32_t tested = 0;
     if (t < total) {
         const uint32_t entry = (t < w.n_prev_closest) ? w.q_prev_closest[t] : w.q_prev_any[t - w.n_prev_closest];
