@@ -879,6 +879,19 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     g.always = c->d_grid_always;
     g.n_always = (uint32_t)always.size();
     g.has_triangles = c->has_triangles ? 1u : 0u;
+    {   // first-cell rule (rt_grid.h: entered_inside; RT_WALK_FIRST_CELL): the ball it uses must stay inside every object's
+        // registration radius by 1e-3 cell (DDA) + the rule's own fp32 rounding (~1e-6 of the largest coordinate)
+        double worst = 0.0;  // max over objects of |pre-test radius| - registration radius (normally about -0.01 cell)
+        bool any = false;
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!(rg[i] >= 0) || !std::isfinite(rg[i])) continue;
+            const double d = std::fabs((double)c->h_grid_pre[i]) - rg[i];
+            worst = any ? std::max(worst, d) : d;
+            any = true;
+        }
+        const double shrink = std::max(0.0, worst + 1e-3 * cell + 2e-6 * (S_max + diag));
+        g.own_shrink = std::nextafter((float)shrink, std::numeric_limits<float>::infinity());
+    }
     g.pretest_alpha = std::nextafter((float)(6e-6 * K2 + 8e-6), std::numeric_limits<float>::infinity());
     g.enabled = 1u;
     c->h_grid_spheres.resize(4 * (size_t)n);
@@ -1305,6 +1318,7 @@ int rt_count_rays(rt_context* c) {
     RT_HIP(c, hipStreamSynchronize(c->stream));
     RT_HIP(c, hipMemcpy(&c->counters, c->d_counters, sizeof(rt::Counters), hipMemcpyDeviceToHost));
     if (std::getenv("RT_WALK_STATS")) {  // engineering aid: what the grid walk did in the counted frame
+        if (c->grid.enabled) std::fprintf(stderr, "[grid] %d x %d x %d cells, edge %g\n", c->grid.nx, c->grid.ny, c->grid.nz, (double)c->grid.cell);
         static const char* names[8] = {"rays", "wave trips", "live lane-trips", "cell fetches", "pre-tests", "exact tests", "exact rounds", "hand-out rounds"};
         for (int k = 0; k < 2; ++k) {
             const unsigned long long* v = c->counters.walk[k];

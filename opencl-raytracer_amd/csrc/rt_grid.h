@@ -55,6 +55,7 @@ struct GridDesc {
     const uint32_t* __restrict__ always;      // objects every ray must test
     uint32_t n_always;
     float pretest_alpha;   // distance-dependent term of the pre-test radius (misses_bounding_sphere)
+    float own_shrink;      // first-cell rule (entered_inside): how much smaller than an entry's |w| the ball is taken (usually 0)
     uint32_t has_triangles;  // the scene holds type-2 records (selects the kernel variants that know them)
     uint32_t enabled;
 };
@@ -153,6 +154,24 @@ __device__ __forceinline__ bool misses_bounding_sphere(const float4 s, const Ray
     if (disc < 0.f) return true;                  // the line misses the sphere
     if (od < 0.f && c > 1.0e-5f * oo) return true;  // centre behind the origin and the origin clearly outside
     return false;                                 // (NaNs compare false: the candidate is tested)
+}
+
+// First-cell rule of the walk (meshes: a triangle is registered in every cell its guard sphere reaches, ~5 of them, and a
+// ray that crosses several of those cells would run the exact test in each). True when the point at which the ray ENTERED
+// the current cell (parameter t_enter >= 0; the first cell of a walk carries a negative one) lies inside the entry's ball
+// of radius |w| - own_shrink. Then the cell the walk was in before - whose wall that point is on, up to the DDA's 1e-4 cell -
+// comes within that radius of the centre, hence holds the object too (own_shrink is chosen on the host such that
+// |w| - own_shrink + 1e-3 cell + this function's own rounding <= the object's registration radius, for every object), the
+// same pre-test passed there (it does not depend on the cell), and by induction the exact test ran - or is parked - in
+// the first cell of that chain, whose entry point is outside the ball or which is the walk's first. Skipping the entry
+// here therefore only drops a REPEATED test: closest_take is order-free and idempotent, an any-hit walk has ended if
+// the test succeeded.
+__device__ __forceinline__ bool entered_inside(const float4 s, const Ray& ray, float t_enter, float own_shrink) {
+    const float px = __builtin_fmaf(t_enter, ray.dx, ray.sx), py = __builtin_fmaf(t_enter, ray.dy, ray.sy), pz = __builtin_fmaf(t_enter, ray.dz, ray.sz);
+    const float ox = s.x - px, oy = s.y - py, oz = s.z - pz;
+    const float a = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float r = __builtin_fabsf(s.w) - own_shrink;
+    return t_enter >= 0.f && r > 0.f && a < r * r;  // (NaN: false - the entry is tested)
 }
 
 // per-lane object test: the HotObject arrives through ordinary (divergent) vector loads
@@ -312,7 +331,7 @@ __device__ __forceinline__ LeanWalk lean_walk(const GridDesc& g, const Walk& w) 
     k.sx = w.stepx > 0 ? 1 : -1;
     k.sy = w.stepy > 0 ? g.nx : -g.nx;
     k.sz = w.stepz > 0 ? g.nx * g.ny : -(g.nx * g.ny);
-    k.t_enter = w.t_enter;
+    k.t_enter = -1.0f;  // "no cell before this one" (entered_inside); the walk only reads t_enter of cells it has stepped into
     return k;
 }
 
@@ -365,8 +384,13 @@ __device__ __forceinline__ void closest_hit_grid(const GridDesc& g, const HotObj
             ++tested;
             if (lane_candidate<FUSED, DW0>(hot + k, ray, t, sphere)) closest_take(t, k, sphere, T, index, cur_sphere);
         }
-        if (!walk_next(g, w)) break;
-        if (w.t_enter > T + slack) break;  // T is +MAX until something is hit
+        // an empty cell's offset word says how many FURTHER steps are sure to land in empty cells (build_grid): those cells are
+        // stepped through without fetching them
+        uint32_t steps = range.y ? 1u : 1u + range.x;
+        bool stop = false;
+        const float limit = T + slack;  // T is +MAX until something is hit
+        while (steps-- != 0u && !stop) stop = !walk_next(g, w) || w.t_enter > limit;
+        if (stop) break;
     }
 }
 
@@ -396,8 +420,10 @@ __device__ __forceinline__ bool any_hit_grid(const GridDesc& g, const Scene& S, 
             ++tested;
             if (lane_candidate<FUSED, true>(hot + (int)g.entries[e], ray, t, sphere) && !(t >= 1.f)) return true;
         }
-        if (!walk_next(g, w)) break;
-        if (w.t_enter > 1.0f + slack) break;
+        uint32_t steps = range.y ? 1u : 1u + range.x;  // (as in closest_hit_grid)
+        bool stop = false;
+        while (steps-- != 0u && !stop) stop = !walk_next(g, w) || w.t_enter > 1.0f + slack;
+        if (stop) break;
     }
     return false;
 }

@@ -377,6 +377,15 @@ constexpr uint32_t kTicketBase = 16;     // counts[16 ..]: closest-hit launch, c
 #ifndef RT_SKIP_CAP
 #define RT_SKIP_CAP 2  // empty-space steps a lane takes per trip beyond the first (the other lanes wait for it; cfg5: 0: 94.7 ms, 2: 91.2, 6: 91.6, 12: 92.1)
 #endif
+#ifndef RT_INLINE_LAST_SHADOW
+#define RT_INLINE_LAST_SHADOW 1  // a path's last hit tests its last-light shadow ray inside wf_resume (shade_last_light_inline)
+#endif
+#ifndef RT_SKIP_FEW_LANES
+#define RT_SKIP_FEW_LANES 12  // ... unless at most this many lanes of the wave are still walking: then as many as the cell allows
+#endif
+#ifndef RT_WALK_FIRST_CELL
+#define RT_WALK_FIRST_CELL 0  // 1: mesh scenes test an entry only in the first cell of the walk that holds it (rt_grid.h: entered_inside). cfg5: exact tests per closest-hit ray 19.7 -> 13.1, frame 64.1 -> 66.7 ms - the rule costs every trip more than the repeated tests did
+#endif
 #ifndef RT_DEFER_PENDING
 #define RT_DEFER_PENDING 8  // run the exact tests once this many lanes hold a candidate ... (8: 20.4, 16: 20.7, 28: 22.9 ms - fewer candidates wait since repeated objects are skipped)
 #endif
@@ -523,6 +532,10 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         }
         bool advance = false, blocked = false;
         uint32_t skip = 0u;
+        // how many of those a lane takes in one trip: few while the wave is full (the other lanes wait for it), all of them
+        // once it is nearly empty - the end of a launch is a handful of rays on their way out of the scene, ~100 dependent
+        // cell fetches each at the old cap, and no launch can be shorter than its longest ray
+        const uint32_t skip_cap = (uint32_t)__popcll(live) <= (uint32_t)RT_SKIP_FEW_LANES ? 255u : (uint32_t)RT_SKIP_CAP;
         if (STATS) { if (lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); } if (st == 1) ++s_fetch; if (st == 2) ++s_pre; }
         // ---- phase A: fetch the current cell's list ----
         if (st == 1) {
@@ -530,7 +543,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             e = range.x;
             e1 = range.x + range.y;
             if (range.y != 0u) st = 2;
-            else { advance = true; skip = range.x < (uint32_t)RT_SKIP_CAP ? range.x : (uint32_t)RT_SKIP_CAP; }  // empty: its offset word says how many further steps stay in empty cells
+            else { advance = true; skip = range.x < skip_cap ? range.x : skip_cap; }  // empty: its offset word says how many further steps stay in empty cells
         }
         // ---- phase B: pre-test one candidate (also for a lane that has just fetched a non-empty cell) ----
         if (st == 2) {
@@ -548,6 +561,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
 #if RT_WALK_DEDUPE
                 if (k == done_k || (pend && k == pend_k)) pass = false;
 #endif
+                if (RT_WALK_FIRST_CELL && TRI && !(ANY && in_lt) && entered_inside(bound, ray, wk.t_enter, g.own_shrink)) pass = false;
             }
             if (pass && pend) {
                 blocked = true;  // one parking slot: wait for the exact tests
@@ -728,6 +742,7 @@ struct Ctx {
     bool pre;
     float4 pre_hit, pre_res, pre_acc;
     Ray pre_ray0;
+    unsigned long long tests = 0;  // exact object tests run by the step itself (last_light_blocked)
 };
 
 template <int KERNEL>
@@ -754,7 +769,105 @@ __device__ __forceinline__ void emit_shadow(Ctx& c, const HitRec& h, uint32_t li
     c.traced += 1;
 }
 
-template <int KERNEL, bool FUSED> __device__ void shade_done(Ctx& c, const HitRec& h, bool primary, float cr, float cg, float cb);
+template <int KERNEL, bool FUSED> __device__ __forceinline__ void shade_done(Ctx& c, const HitRec& h, bool primary, float cr, float cg, float cb);
+__device__ __forceinline__ void finish_reflect(Ctx& c, bool fused, float abr, float abg, float abb, float rr, float rg, float rb, float ap, uint32_t bounces);
+
+// Is the shadow ray towards the LAST light (the light of the light tiles) blocked? One thread, the whole list: the same
+// tile, the same cut, the same pre-test and the same exact tests as the light-tile mode of the persistent walk
+// (trace_segment, in_lt) - an any-hit answer does not depend on the order or on who asks. (Light tiles are only built for
+// scenes without always-tested objects: build_light_tiles.)
+template <bool FUSED>
+__device__ __forceinline__ bool last_light_blocked(const WfParams& w, Ray ray, uint32_t& tests) {
+    ray.sw = 1.0f; ray.dw = 0.0f;  // as the walk's hand-out (rt_create checks the preconditions of a grid-able frame)
+    const HotObject* __restrict__ hot = w.rp.scene.hot;
+    const float chk = ((ray.sx + ray.sy) + ray.sz) + ((ray.dx + ray.dy) + ray.dz);
+    uint32_t tile;
+    float cut;
+    if (chk == chk && light_tile_of(w.ltiles, ray.sx, ray.sy, ray.sz, tile, cut)) {
+        const float dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
+        const uint2 range = table_at(w.ltiles.tile_range, tile);
+        for (uint32_t e = range.x; e != range.x + range.y; ++e) {
+            const float4 bound = table_at(w.ltiles.records, 2u * e), aux = table_at(w.ltiles.records, 2u * e + 1u);
+            if (aux.x > cut) break;  // sorted by distance from the light: this entry and all after it lie beyond the ray's origin
+            if (misses_bounding_sphere(bound, ray, dd, w.grid.pretest_alpha)) continue;
+            float t;
+            bool sphere;
+            ++tests;
+            if (lane_candidate<FUSED, true, true>(hot + __float_as_uint(aux.y), ray, t, sphere) && !(t >= 1.f)) return true;
+        }
+        return false;
+    }
+    return nan_shadow_blocked(w.rp.scene, ray);  // no tile in that direction: nothing in the way - unless the ray is a NaN ray
+}
+
+// shade_and_reflect, a hit that sends no reflection ray (its path ends here: no bounces left, or absorbed): nothing else of
+// the pixel would be in flight next to its shadow ray, and the whole frame would go through one more round - a shadow
+// walk, a wf_resume pass - for the last hit of every path. With light tiles the last light's shadow test is a short list:
+// it is run HERE, and the light loop's backward scan (shade_last_light_wins) finishes on the spot. False (nothing done,
+// nothing counted) when the scan has to go on to an earlier light (stale specular: lit, nDotL <= 0) - the queued path takes over.
+template <bool FUSED>
+__device__ __forceinline__ bool shade_last_light_inline(Ctx& c, const HitRec& h, bool primary) {
+    const Scene& S = c.w.rp.scene;
+    const uint32_t li = S.n_lights - 1u;
+    float nDotL, rDotV;
+    bool lit;
+    uint32_t tests = 0;
+    {   // the shadow test first, with as little else alive as possible (the step runs at 4 waves per SIMD, 128 registers)
+        float nvx = h.nx, nvy = h.ny, nvz = h.nz;
+        normalize3(nvx, nvy, nvz);
+        float vvx = -h.px, vvy = -h.py, vvz = -h.pz;
+        normalize3(vvx, vvy, vvz);
+        LightGeom g;
+        light_geometry<FUSED>(S.lights[li], h, nvx, nvy, nvz, vvx, vvy, vvz, g);
+        nDotL = g.nDotL; rDotV = g.rDotV;
+        lit = !last_light_blocked<FUSED>(c.w, g.shadow, tests);
+    }
+    const LightRec L = S.lights[li];
+    const ColdObject* co = S.cold + h.index;
+    const float4 amb = co->amb_absorb, dif = co->dif_shine, spec = co->spec_type;
+    // (resume_shadow's backward scan at its first light, statement for statement)
+    float dr = 0.f, dg = 0.f, db = 0.f, sr = 0.f, sg = 0.f, sb = 0.f;
+    const float ar = amb.x * L.ambient.x, ag = amb.y * L.ambient.y, ab = amb.z * L.ambient.z;
+    if (lit) {
+        const float nd = __builtin_fmaxf(nDotL, 0.f);
+        dr = (dif.x * L.diffuse.x) * nd; dg = (dif.y * L.diffuse.y) * nd; db = (dif.z * L.diffuse.z) * nd;
+    }
+    bool need_specular = true;
+    if (!lit) {
+        need_specular = false;
+    } else if (nDotL > 0) {
+        const float pw = specular_power(rDotV, dif.w);
+        sr = (spec.x * L.specular.x) * pw; sg = (spec.y * L.specular.y) * pw; sb = (spec.z * L.specular.z) * pw;
+        need_specular = false;
+    }
+    if (need_specular && li > 0u) return false;
+    const float cr = (ar + dr) + sr, cg = (ag + dg) + sg, cb = (ab + db) + sb;
+    // shade_done() and the top of loop_step(), written out: this function is reached FROM loop_step (via begin_shade_lit),
+    // and going back into it would make the call graph recursive (a device stack of unknown depth). The path ends here.
+    float abr, abg, abb, rr, rg, rb, ap;
+    uint32_t bounces;
+    if (primary) {
+        ap = amb.w;
+        abr = cr * ap; abg = cg * ap; abb = cb * ap;
+        rr = 0.f; rg = 0.f; rb = 0.f;
+        bounces = c.w.rp.max_bounces;
+    } else {
+        const float4 acc = c.pre ? c.pre_acc : load_block(c.w, F_ABR, c.i);
+        ap = acc.w;
+        abr = acc.x; abg = acc.y; abb = acc.z;
+        const float ra = (1.f - ap) * amb.w;
+        abr = fma_<FUSED>(ra, cr, abr); abg = fma_<FUSED>(ra, cg, abg); abb = fma_<FUSED>(ra, cb, abb);
+        ap = ap + ra;
+        rr = cr; rg = cg; rb = cb;
+        bounces = c.pre ? __float_as_uint(c.pre_res.w) : U(c.w, F_BOUNCES, c.i);
+    }
+    if (bounces > 0u && ap <= 0.999f) return false;  // the loop would go on (the caller's `sends` says it cannot): not this function's case
+    c.traced += 1;
+    c.tests += tests;
+    if (bounces > 0u) c.reference += 1;  // (loop_step: the iteration whose absorption test ends the loop)
+    finish_reflect(c, FUSED, abr, abg, abb, rr, rg, rb, ap, bounces - 1u);
+    return true;
+}
 
 // Start shading hit `h` when there is at least one light (light loop of shade(), shade_and_reflect_kernel.cl:193):
 // queue the first shadow ray. In shade_and_reflect the reflection ray that leaves this hit depends on the hit and
@@ -771,7 +884,11 @@ __device__ __forceinline__ void begin_shade_lit(Ctx& c, const HitRec& h, bool pr
     // shade_and_reflect outside literal mode never needs the stored reflection vector: either the ray leaves now, or
     // loop_step() will decide - under this same condition - that there is none
     if (!(KERNEL == 2 && !S.literal)) store_hit_extra(c.w, c.i, h);
-    if (KERNEL == 2 && !S.literal && spec_bounces > 0u && spec_ap <= 0.999f) {
+    const bool sends = KERNEL == 2 && !S.literal && spec_bounces > 0u && spec_ap <= 0.999f;
+    if (KERNEL == 2 && RT_INLINE_LAST_SHADOW && !S.literal && !sends && c.w.ltiles.enabled && S.n_lights - 1u == c.w.ltiles.light) {
+        if (shade_last_light_inline<FUSED>(c, h, primary)) return;
+    }
+    if (sends) {
         Ray ray;
         reflection_ray<FUSED>(h, ray);
         if (c.w.grid.enabled) {
@@ -947,6 +1064,10 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
         HitRec rh;
         materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
         store_loop_state(c, abr, abg, abb, rr, rg, rb, ap, bounces, false);
+        if (c.pre) {  // the step may go on to shade rh on the spot (shade_last_light_inline): what it preloaded is now this
+            c.pre_acc = make_float4(abr, abg, abb, ap);
+            c.pre_res.w = __uint_as_float(bounces);
+        }
         const float ra = (1.f - ap) * S.cold[rh.index].amb_absorb.w;  // shade_done's update, ahead of time
         begin_shade_lit<2, FUSED>(c, rh, false, bounces, ap + ra);
         return;
@@ -962,7 +1083,7 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
 }
 
 template <int KERNEL, bool FUSED>
-__device__ void shade_done(Ctx& c, const HitRec& h, bool primary, float cr, float cg, float cb) {
+__device__ __forceinline__ void shade_done(Ctx& c, const HitRec& h, bool primary, float cr, float cg, float cb) {
     const Scene& S = c.w.rp.scene;
     if (KERNEL == 1) { write_pixel<1>(c, cr, cg, cb); return; }
     const uint64_t i = c.i;
@@ -1046,11 +1167,12 @@ __device__ __forceinline__ bool duplicate_entry(const WfParams& w, uint32_t t, u
 }
 
 __device__ __forceinline__ void add_ray_counters(const WfParams& w, const Ctx& c) {
-    const unsigned long long a = wave_sum64(c.traced), b = wave_sum64(c.reference), h = wave_sum64(c.hits);
-    if ((threadIdx.x & 63u) == 0u && (a | b | h)) {
+    const unsigned long long a = wave_sum64(c.traced), b = wave_sum64(c.reference), h = wave_sum64(c.hits), t = wave_sum64(c.tests);
+    if ((threadIdx.x & 63u) == 0u && (a | b | h | t)) {
         atomicAdd(&w.rp.counters->traced, a);
         atomicAdd(&w.rp.counters->reference, b);
         atomicAdd(&w.rp.counters->hits, h);
+        if (t) atomicAdd(&w.rp.counters->tests, t);
     }
 }
 
@@ -1098,7 +1220,10 @@ __global__ __launch_bounds__(256) void wf_finish(const WfParams wk) {
             for (;;) {
                 if (do_any) {
                     const Ray ray = load_ray(w, c.i, kSlotShadow);
-                    U(w, F_RES_ANY, c.i) = any_hit_grid<FUSED>(w.grid, w.rp.scene, ray, tested) ? 0u : 1u;
+                    const bool blocked = (w.ltiles.enabled && __float_as_uint(ray.dw) == w.ltiles.light)
+                                             ? last_light_blocked<FUSED>(w, ray, tested)   // (the walk's choice: trace_segment)
+                                             : any_hit_grid<FUSED>(w.grid, w.rp.scene, ray, tested);
+                    U(w, F_RES_ANY, c.i) = blocked ? 0u : 1u;
                 }
                 if (do_closest) {
                     const Ray ray = load_ray(w, c.i, kSlotClosest);

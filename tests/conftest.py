@@ -2,6 +2,7 @@ import sys
 from pathlib import Path
 
 import pytest
+import torch  # noqa: F401  (before anything loads libhip_raytracer.so: torch ships its own ROCm runtime, and initialising it after the system one has been loaded into the process fails with "No HIP GPUs are available")
 
 ROOT = Path(__file__).resolve().parent.parent
 for p in (str(ROOT), str(ROOT / "tests")):

@@ -3,7 +3,7 @@
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if "rt::" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if "wf_begin" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "wf_begin" in r["Kernel_Name"] or "wf_identity_round" in r["Kernel_Name"]]
 fr = rows[starts[-1]:] if starts else rows[-1:]
 t0 = int(fr[0]["Start_Timestamp"])
 for r in fr:
