@@ -536,7 +536,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         // once it is nearly empty - the end of a launch is a handful of rays on their way out of the scene, ~100 dependent
         // cell fetches each at the old cap, and no launch can be shorter than its longest ray
         const uint32_t skip_cap = (uint32_t)__popcll(live) <= (uint32_t)RT_SKIP_FEW_LANES ? 255u : (uint32_t)RT_SKIP_CAP;
-        if (STATS) { if (lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); } if (st == 1) ++s_fetch; if (st == 2) ++s_pre; }
+        if (STATS) { if (lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); } if (st == 1) ++s_fetch; }
         // ---- phase A: fetch the current cell's list ----
         if (st == 1) {
             const uint2 range = table_at(g.cell_range, (uint32_t)wk.c);
@@ -550,6 +550,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             float4 bound, aux = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ANY && in_lt) { bound = table_at(w.ltiles.records, 2u * e); aux = table_at(w.ltiles.records, 2u * e + 1u); }
             else bound = table_at(g.entry_sphere, e);
+            if (STATS) ++s_pre;
             bool pass = !misses_bounding_sphere(bound, ray, dd, g.pretest_alpha);
             if (ANY && in_lt && aux.x > slack) {  // sorted by distance from the light: this entry and all after it lie beyond the ray's origin
                 pass = false;
