@@ -175,7 +175,7 @@ def measure_brute_force_window(device_index, edge):
     valu = st.object_tests * SPHERE_TEST_LANE_OPS / (kernel_ms * 1e-3)
     res = {"workload": ("same frame" if edge >= W else f"same scene, centred {edge}x{edge} window of the 4096x4096 grid") +
                        ", every object tested for every ray (RT_FLAG_NO_GRID)",
-           "kernel": "rt::wf_trace_closest + rt::wf_trace_any_slice (+ wf_resume, wf_begin)",
+           "kernel": "rt::wf_trace_closest + rt::wf_trace_any_slice (+ wf_resume)",
            "value": st.rays_reference / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
            "bound": "valu", "achieved": valu / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "roofline_unit": "T lane-instr/s",
            "frac": valu / VALU_PEAK_LANE_OPS, "object_tests": int(st.object_tests),
@@ -379,7 +379,7 @@ def main():
             out["roofline"] = {"bound": "valu", "achieved": valu / 1e12, "peak": VALU_PEAK_LANE_OPS * world / 1e12,
                                "unit": "T lane-instr/s", "frac": valu / (VALU_PEAK_LANE_OPS * world), "traffic": traffic,
                                "kernel": ("rt::wf_trace_grid_persistent<closest|any> + rt::wf_trace_primary_tiles" if culled else
-                                          "rt::wf_trace_closest + rt::wf_trace_any_slice") + " (+ wf_resume, wf_begin)",
+                                          "rt::wf_trace_closest + rt::wf_trace_any_slice") + " (+ wf_resume)",
                                "kernel_ms": kernel_ms, "object_tests": tests,
                                "tests_per_s": tests / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0, "hbm": hbm}
             if culled and prof:
@@ -411,7 +411,7 @@ def main():
                 if world == 1 and not args.no_extra:
                     out["roofline"]["brute_force"] = measure_brute_force_window(local_rank, 4096)
         elif args.workload == "cfg5":
-            hbm["kernel"] = "rt::wf_trace_grid_persistent<closest|any> + rt::wf_trace_primary_tiles (+ wf_resume, wf_begin)"
+            hbm["kernel"] = "rt::wf_trace_grid_persistent<closest|any> + rt::wf_trace_primary_tiles (+ wf_resume)"
             hbm["note"] = ("triangles are this repo's extension (no reference semantics; SURVEY.md 8f5 defines no per-test work "
                            "figure for them): the mandated HBM figure only - the frame is bound by the grid walk's instruction "
                            "issue, like cfg4")

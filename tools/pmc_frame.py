@@ -26,10 +26,11 @@ def find(sub, pattern):
 
 
 def last_frame_rows(rows, key_id):
-    """rows of our kernels from the last wf_begin on (large scenes) or the last launch (small scenes)"""
+    """rows of our kernels from the last frame start on (large scenes: wf_identity_round, or wf_begin for frames with
+    padding work-items) or the last launch (small scenes)"""
     ours = [r for r in rows if "rt::" in r["Kernel_Name"]]
     ours.sort(key=lambda r: int(r[key_id]))
-    starts = [i for i, r in enumerate(ours) if "wf_begin" in r["Kernel_Name"]]
+    starts = [i for i, r in enumerate(ours) if "wf_begin" in r["Kernel_Name"] or "wf_identity_round" in r["Kernel_Name"]]
     if starts:
         first_id = int(ours[starts[-1]][key_id])
         return [r for r in ours if int(r[key_id]) >= first_id]
