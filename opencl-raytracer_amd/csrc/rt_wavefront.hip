@@ -1309,7 +1309,11 @@ size_t wavefront_counter_bytes() { return sizeof(uint32_t) * (size_t)(kTicketBas
 // queue can hold, the kernel reads its real length from the round state
 template <bool FUSED, bool ANY>
 static void launch_persistent(const WfParams& w, uint64_t n_max, uint32_t* ticket, hipStream_t s, bool shared) {
-    const dim3 grid = persistent_grid(n_max, shared ? (ANY ? RT_MAX_WAVES_ANY_SHARED : RT_MAX_WAVES_CLOSEST_SHARED) : RT_MAX_WAVES), block(256);
+    // The shadow walk (light tiles: two or three short trips per ray) is bound by what a wave costs to start, not by how many
+    // rays are in flight: MEASURED, rank 0's share of the cfg4 frame at world = 1 / 2 / 4 / 8 with its wave cap at 8192:
+    // 17.44 / 9.51 / 5.57 / 3.59 ms; 4096: 17.40 / 9.34 / 5.31 / 3.39; 2048: 18.15 / 9.57 / 5.36 / 3.32; 1024: 20.2 / 10.6 / 5.9 / 3.56.
+    const uint64_t any_cap = std::min<uint64_t>(RT_MAX_WAVES_ANY_SHARED, n_max <= (3ull << 20) ? 2048u : 4096u);
+    const dim3 grid = persistent_grid(n_max, ANY ? any_cap : (shared ? RT_MAX_WAVES_CLOSEST_SHARED : RT_MAX_WAVES)), block(256);
     const bool tri = w.grid.has_triangles != 0u;
     if (w.count_rays) {
         if (tri) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, true, true>), grid, block, 0, s, w, ticket);
