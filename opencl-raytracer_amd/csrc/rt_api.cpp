@@ -66,6 +66,7 @@ struct rt_context {
 
     rt::GridDesc grid = {};                 // device pointers owned by this context
     uint2* d_grid_cell_range = nullptr;
+    float4* d_grid_cell_rec = nullptr;
     uint32_t* d_grid_entries = nullptr;
     uint32_t* d_grid_always = nullptr;
     float4* d_grid_entry_sphere = nullptr;
@@ -807,7 +808,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
             for (size_t k = 0; k < n_cells; ++k) start[k + 1] += start[k];
             total = start[n_cells];
             // the kernels address these tables with 32-bit byte offsets (table_at)
-            if ((uint64_t)total * 16ull >= 0xffffffffull || (uint64_t)n_cells * 8ull >= 0xffffffffull) return RT_OK;
+            if ((uint64_t)total * 16ull >= 0xffffffffull || (uint64_t)n_cells * 32ull >= 0xffffffffull) return RT_OK;
         } else {
             RT_HIP(c, hipMalloc((void**)&c->d_grid_entries, sizeof(uint32_t) * (total + 1)));
             RT_HIP(c, hipMalloc((void**)&c->d_grid_always, sizeof(uint32_t) * (always.size() + 1)));
@@ -862,6 +863,20 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
                 }
                 RT_HIP(c, hipMalloc((void**)&c->d_grid_cell_range, sizeof(uint2) * n_cells));
                 RT_HIP(c, hipMemcpy(c->d_grid_cell_range, ranges.data(), sizeof(uint2) * n_cells, hipMemcpyHostToDevice));
+                // the same ranges with the first entry inline (the persistent walk's 32-byte cell records; the kernel variants
+                // for scenes without triangles read these, the mesh variants the 8-byte ranges: a mesh leaves its grid mostly
+                // empty, and an empty cell has nothing to inline)
+                if (!c->has_triangles) {
+                    std::vector<float4> rec(2 * n_cells);
+                    for (size_t k = 0; k < n_cells; ++k) {
+                        const bool any = ranges[k].y != 0u;
+                        rec[2 * k] = any ? es[ranges[k].x] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        uint32_t w[4] = {ranges[k].x, ranges[k].y, any ? entries[ranges[k].x] : 0u, 0u};
+                        std::memcpy(&rec[2 * k + 1], w, sizeof(w));
+                    }
+                    RT_HIP(c, hipMalloc((void**)&c->d_grid_cell_rec, sizeof(float4) * 2 * n_cells));
+                    RT_HIP(c, hipMemcpy(c->d_grid_cell_rec, rec.data(), sizeof(float4) * 2 * n_cells, hipMemcpyHostToDevice));
+                }
             }
             if (total) RT_HIP(c, hipMemcpy(c->d_grid_entries, entries.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
             if (!always.empty())
@@ -874,6 +889,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     g.inv_cell = 1.0f / cellf;
     g.nx = dim[0]; g.ny = dim[1]; g.nz = dim[2];
     g.cell_range = c->d_grid_cell_range;
+    g.cell_rec = c->d_grid_cell_rec;
     g.entries = c->d_grid_entries;
     g.entry_sphere = c->d_grid_entry_sphere;
     g.always = c->d_grid_always;
@@ -1386,6 +1402,7 @@ void rt_destroy(rt_context* c) {
     if (c->d_cold) (void)hipFree(c->d_cold);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
     if (c->d_grid_cell_range) (void)hipFree(c->d_grid_cell_range);
+    if (c->d_grid_cell_rec) (void)hipFree(c->d_grid_cell_rec);
     if (c->d_grid_entries) (void)hipFree(c->d_grid_entries);
     if (c->d_grid_always) (void)hipFree(c->d_grid_always);
     if (c->d_grid_entry_sphere) (void)hipFree(c->d_grid_entry_sphere);

@@ -50,6 +50,9 @@ struct GridDesc {
     int nx, ny, nz;
     const uint2* __restrict__ cell_range;     // nx*ny*nz x {first entry, number of entries}; an EMPTY cell's first word is
                                               // the number of further walk steps that are sure to stay in empty cells
+    const float4* __restrict__ cell_rec;      // nx*ny*nz x 32 bytes for the persistent walk: [0] the bounding sphere of the cell's FIRST
+                                              // entry, [1] bits {first entry, number of entries, object of the first entry, 0} - the
+                                              // range and the first candidate arrive with ONE request (RT_CELL_INLINE)
     const uint32_t* __restrict__ entries;     // object indices, ascending inside a cell
     const float4* __restrict__ entry_sphere;  // parallel to entries: the object's inflated bounding sphere (centre, R_grid)
     const uint32_t* __restrict__ always;      // objects every ray must test

@@ -380,6 +380,11 @@ constexpr uint32_t kTicketBase = 16;     // counts[16 ..]: closest-hit launch, c
 #ifndef RT_INLINE_LAST_SHADOW
 #define RT_INLINE_LAST_SHADOW 1  // a path's last hit tests its last-light shadow ray inside wf_resume (shade_last_light_inline)
 #endif
+#ifndef RT_CELL_INLINE
+#define RT_CELL_INLINE 1  // the persistent walk reads 32-byte cell records that hold the first entry (GridDesc::cell_rec) - range and first
+                          // candidate in ONE request instead of two dependent ones: cfg4 17.5 -> 17.0 ms. Not for sparsely occupied
+                          // grids (meshes): four times the bytes per EMPTY cell cost cfg5 60.4 -> 62.6 ms
+#endif
 #ifndef RT_SKIP_FEW_LANES
 #define RT_SKIP_FEW_LANES 12  // ... unless at most this many lanes of the wave are still walking: then as many as the cell allows
 #endif
@@ -538,8 +543,20 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         const uint32_t skip_cap = (uint32_t)__popcll(live) <= (uint32_t)RT_SKIP_FEW_LANES ? 255u : (uint32_t)RT_SKIP_CAP;
         if (STATS) { if (lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); } if (st == 1) ++s_fetch; }
         // ---- phase A: fetch the current cell's list ----
+        bool fresh = false;                // this trip fetched the lane's cell: its first candidate came with the record
+        float4 first = make_float4(0.f, 0.f, 0.f, 0.f);
+        uint32_t first_k = 0u;
         if (st == 1) {
-            const uint2 range = table_at(g.cell_range, (uint32_t)wk.c);
+            uint2 range;
+            if (RT_CELL_INLINE && !TRI) {  // (compile-time: with both forms in one kernel - a run-time switch - the frame took 18.6 ms)
+                const float4 r1 = table_at(g.cell_rec, 2u * (uint32_t)wk.c + 1u);
+                first = table_at(g.cell_rec, 2u * (uint32_t)wk.c);
+                range = make_uint2(__float_as_uint(r1.x), __float_as_uint(r1.y));
+                first_k = __float_as_uint(r1.z);
+                fresh = range.y != 0u;
+            } else {
+                range = table_at(g.cell_range, (uint32_t)wk.c);
+            }
             e = range.x;
             e1 = range.x + range.y;
             if (range.y != 0u) st = 2;
@@ -549,6 +566,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         if (st == 2) {
             float4 bound, aux = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ANY && in_lt) { bound = table_at(w.ltiles.records, 2u * e); aux = table_at(w.ltiles.records, 2u * e + 1u); }
+            else if (RT_CELL_INLINE && fresh) bound = first;
             else bound = table_at(g.entry_sphere, e);
             if (STATS) ++s_pre;
             bool pass = !misses_bounding_sphere(bound, ray, dd, g.pretest_alpha);
@@ -558,7 +576,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             }
             uint32_t k = 0u;
             if (pass) {  // the same object again (parked, or tested a cell ago)? its result is known or on its way
-                k = (ANY && in_lt) ? __float_as_uint(aux.y) : table_at(g.entries, e);
+                k = (ANY && in_lt) ? __float_as_uint(aux.y) : ((RT_CELL_INLINE && fresh) ? first_k : table_at(g.entries, e));
 #if RT_WALK_DEDUPE
                 if (k == done_k || (pend && k == pend_k)) pass = false;
 #endif
