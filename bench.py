@@ -274,22 +274,28 @@ def main():
 
     from opencl_raytracer_amd.distributed import ShardedHIPRaytracer
     from opencl_raytracer_amd.hip_raytracer import HIPRaytracer  # noqa: F401
+    # N > 1 over RCCL: frame k's tiles travel to rank 0 and are put in place while frame k + 1 is being rendered
+    # (distributed.FrameGather, pipelined mode; all of it inside the timed region, which ends with a device-wide sync).
+    # RT_BENCH_PIPELINE=0: render, exchange, assemble one after the other. The gloo rehearsal stages through host memory anyway.
+    # RT_BENCH_PIPELINE=force: also in the rehearsal (the same code path end to end on a one-GPU box).
+    _pl = os.environ.get("RT_BENCH_PIPELINE", "1")
+    pipeline = world > 1 and ((dist.get_backend() == "nccl" and _pl != "0") or _pl == "force")
 
     if crop is not None:
         rays = camera.crop_rays(W, H, *crop)
         rt = ShardedHIPRaytracer(objs, lights, rays, depth, kernel=kernel, tile_rows=args.tile_rows, width=crop[2],
-                                 device_index=local_rank, literal=args.literal, grid=not args.no_grid)
+                                 device_index=local_rank, pipeline=pipeline, literal=args.literal, grid=not args.no_grid)
         frame_w, frame_h = crop[2], crop[3]
         ray_source = "buffer"
     elif args.ray_buffer:
         rays = camera.primary_rays(W, H)
         rt = ShardedHIPRaytracer(objs, lights, rays, depth, kernel=kernel, tile_rows=args.tile_rows, width=W,
-                                 device_index=local_rank, literal=args.literal, raygen=False, grid=not args.no_grid)
+                                 device_index=local_rank, pipeline=pipeline, literal=args.literal, raygen=False, grid=not args.no_grid)
         frame_w, frame_h = W, H
         ray_source = "buffer"
     else:
         rt = ShardedHIPRaytracer(objs, lights, None, depth, camera=(W, H, z), kernel=kernel, tile_rows=args.tile_rows,
-                                 device_index=local_rank, literal=args.literal, grid=not args.no_grid)
+                                 device_index=local_rank, pipeline=pipeline, literal=args.literal, grid=not args.no_grid)
         frame_w, frame_h = W, H
         ray_source = "in-kernel pinhole"
     n_rays = rt.n_rays
@@ -350,7 +356,8 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": desc, "width": frame_w, "height": frame_h, "objects": int(len(objs)),
                        "lights": int(len(lights)), "kernel": kernel, "depth": depth, "primary_rays": ray_source,
-                       "partition": f"row-tiles of {args.tile_rows} rows, interleaved over {world} rank(s), gather to rank 0"
+                       "partition": (f"row-tiles of {args.tile_rows} rows, interleaved over {world} rank(s), gather to rank 0"
+                                     + (", frame k's exchange overlapped with frame k+1's render" if pipeline else ""))
                        if world > 1 else "single GPU", "arithmetic": "fused (fma where the OpenCL front-end marks fmuladd)",
                        "literal": bool(args.literal)},
             # `value` counts the rays the REFERENCE semantics trace for the frame (R_ref); what this backend

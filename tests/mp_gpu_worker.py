@@ -36,20 +36,30 @@ def main():
     for n_objs, (W, H, tile_rows) in ((12, (256, 128, 16)), (600, (256, 128, 16)), (600, (192, 104, 8))):
         objs, lights = synthetic.spheres_and_lights(n_objs, 3)
         z = float(camera.camera_z(H))
-        srt = ShardedHIPRaytracer(objs, lights, None, 3, camera=(W, H, z), tile_rows=tile_rows, device_index=local_rank)
-        for _ in range(2):
-            frame = srt.Render()
+        want = None
         if rank == 0:
-            got = frame.cpu().numpy()
             with HIPRaytracer(objs, lights, None, 3, camera=(W, H, z), device=local_rank) as rt:
                 want = rt.Render()
-            same = got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
-            print(f"[rank 0] {backend} world {world} N={n_objs} {W}x{H} tile_rows {tile_rows}: {'ok' if same else 'MISMATCH'}", flush=True)
-            ok = ok and same
-        else:
-            assert frame is None
-        srt.close()
-        dist.barrier()
+        for pipeline in (False, True):
+            # pipelined: frame k's exchange overlaps frame k + 1's render (two slots of every buffer, three streams); five
+            # frames, every one checked, every buffer poisoned with NaN before it is reused
+            srt = ShardedHIPRaytracer(objs, lights, None, 3, camera=(W, H, z), tile_rows=tile_rows, device_index=local_rank,
+                                      pipeline=pipeline)
+            srt.gatherer.debug_poison = pipeline
+            same = True
+            for _ in range(5 if pipeline else 2):
+                frame = srt.Render()
+                if rank == 0:
+                    got = frame.cpu().numpy()   # (on the current stream: ordered behind the frame's assembly)
+                    same = same and got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+                else:
+                    assert frame is None
+            if rank == 0:
+                print(f"[rank 0] {backend} world {world} N={n_objs} {W}x{H} tile_rows {tile_rows} pipeline {pipeline}: "
+                      f"{'ok' if same else 'MISMATCH'}", flush=True)
+                ok = ok and same
+            srt.close()
+            dist.barrier()
     flag = torch.tensor([1 if ok else 0])
     if backend == "nccl":
         flag = flag.cuda()

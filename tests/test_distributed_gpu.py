@@ -25,7 +25,7 @@ def _run(backend, world):
            "--master-port", str(port), str(ROOT / "tests" / "mp_gpu_worker.py"), backend]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
-    assert res.stdout.count(": ok") == 3 and "MISMATCH" not in res.stdout, res.stdout
+    assert res.stdout.count(": ok") == 6 and "MISMATCH" not in res.stdout, res.stdout  # 3 scenes x {synchronous, pipelined}
 
 
 @pytest.mark.parametrize("world", [2, 3])
