@@ -145,6 +145,30 @@ def test_triangle_soup_fuzz_vs_oracle(restatement, seed):
     assert int((want["hit_index"] >= 0).sum()) > m // 10
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_soup_lit_from_outside_by_the_last_of_three_lights(restatement, seed):
+    """The last light far outside the soup (the light tiles are built, a path's last hit tests its shadow ray inside
+    wf_resume), two more lights inside it. Triangles are two-sided: many hits are LIT with nDotL <= 0, where the backward
+    light scan has to go on to the earlier lights - the in-resume test must hand those back to the queued path. Depth 4,
+    absorbing and reflective materials, so that paths end by absorption, by exhaustion and by escaping."""
+    rng = np.random.default_rng(900 + seed)
+    n = 1200
+    spread = 6.0
+    size = rng.choice([0.05, 0.4, 1.5], size=n)[:, None]
+    c = rng.uniform(-spread, spread, (n, 3)) + np.array([0.0, 0.0, -30.0])
+    v0, v1, v2 = (c + rng.normal(size=(n, 3)) * size for _ in range(3))
+    tmpl = R.make_object(R.SPHERE, R.Material((.2, .3, .4), (.5, .5, .5), (.3, .3, .3), absorption=0.5, shininess=5), np.eye(4, dtype=np.float32))
+    tri = T.triangle_records(v0, v1, v2, tmpl)
+    tri["absorption"] = rng.choice([0.2, 0.6, 1.0], size=n).astype(np.float32)
+    props = R.LightProperties((.2, .2, .2), (.5, .5, .5), (.5, .5, .5))
+    inside = [tuple(rng.uniform(-spread, spread, 3) + np.array([0.0, 0.0, -30.0])) for _ in range(2)]
+    lights = R.lights_array([R.make_light(props, position=(*inside[0], 1.0)), R.make_light(props, position=(*inside[1], 1.0)),
+                             R.make_light(props, position=(3.0, 60.0, -25.0, 1.0))])
+    rays = camera.primary_rays(64, 48)
+    want = _check(tri, lights, rays, 4, restatement[True], kernels=("shade_and_reflect",))
+    assert int((want["hit_index"] >= 0).sum()) > 300
+
+
 def test_config5_million_triangles_8192_properties(restatement):
     """BASELINE configs[4] at full size: roundedCube.txt tessellated to ~1 M triangles, 8192 x 8192, depth 5. The CPU
     statement tests every triangle for every ray, so it checks a 16 x 16 window of the frame (nearest t, index and
