@@ -455,7 +455,7 @@ int ensure_wavefront(rt_context* c) {
     return RT_OK;
 }
 
-int build_screen_tiles(rt_context* c, hipStream_t stream);
+int build_screen_tiles(rt_context* c, hipStream_t stream, uint32_t col_shift);
 
 int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     if (c->n_local == 0) {  // empty launch: nothing to render, nothing to time
@@ -528,8 +528,10 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     if (c->last_wavefront) {  // one-time host-side set-up (buffers, per-camera screen tiles) stays outside the timed region
         int rc = ensure_wavefront(c);
         if (rc) return rc;
-        if (c->tiles_dirty) {
-            rc = build_screen_tiles(c, stream);
+        // a first-round wave is an 8 x 8 block of pixels (work-items in tile order) or 64 pixels of one row: the tile lists follow
+        const uint32_t col_shift = p.wf_tile_order ? 3u : 6u;
+        if (c->tiles_dirty || (c->tiles.enabled && c->tiles.col_shift != col_shift)) {
+            rc = build_screen_tiles(c, stream, col_shift);
             if (rc) return rc;
         }
         c->wf.tiles = c->tiles;
@@ -549,15 +551,18 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     return RT_OK;
 }
 
-// Primary rays of a pinhole grid: per screen tile (64 x 8 pixels) the objects whose conservative screen rectangle
-// (projection of the grid sphere, i.e. with the same error-bound inflation) overlaps the tile, ascending index.
-// A wave of the first trace round holds 64 consecutive pixels of one row = one tile, so it walks that list with
-// wave-uniform scalar loads instead of 64 separate grid walks.
-int build_screen_tiles(rt_context* c, hipStream_t stream) {
+// Primary rays of a pinhole grid: per screen tile the objects whose conservative screen rectangle (projection of the grid
+// sphere, i.e. with the same error-bound inflation) overlaps the tile, ascending index. A wave of the first trace round
+// holds the 64 pixels of ONE tile - an 8 x 8 block (col_shift 3) when the work-items walk the frame in such blocks, else 64
+// consecutive pixels of a row inside a 64 x 8 tile (col_shift 6) - so it walks that list with wave-uniform scalar loads
+// instead of 64 separate grid walks. (Round 2: 8 x 8 tiles instead of 64 x 8 wherever the order allows - a wave no longer
+// tests what only the seven other blocks of its 64 x 8 tile can see.)
+int build_screen_tiles(rt_context* c, hipStream_t stream, uint32_t col_shift) {
     c->tiles = rt::ScreenTiles{};
     c->tiles_dirty = false;
-    if (!c->grid.enabled || !c->pinhole || !(c->z < 0.f) || c->width % 64u != 0 || c->h_grid_spheres.empty()) return RT_OK;
-    const uint32_t tx = c->width / 64u, ty = (c->height + 7u) / 8u;
+    const uint32_t tile_w = 1u << col_shift;
+    if (!c->grid.enabled || !c->pinhole || !(c->z < 0.f) || c->width % tile_w != 0 || c->h_grid_spheres.empty()) return RT_OK;
+    const uint32_t tx = c->width / tile_w, ty = (c->height + 7u) / 8u;
     const size_t n_tiles = (size_t)tx * ty;
     const uint32_t n = c->n_objs;
     const double half_w = (double)((float)c->width / 2.0f), half_h = (double)((float)c->height / 2.0f), H = (double)c->height;
@@ -585,7 +590,7 @@ int build_screen_tiles(rt_context* c, hipStream_t stream) {
         const double cx0 = std::max(0.0, std::floor(c0)), cx1 = std::min((double)c->width - 1, std::ceil(c1));
         const double ry0 = std::max(0.0, std::floor(r0)), ry1 = std::min((double)c->height - 1, std::ceil(r1));
         if (cx0 > cx1 || ry0 > ry1) continue;
-        const int x0 = (int)(cx0 / 64), x1 = (int)(cx1 / 64), y0 = (int)(ry0 / 8), y1 = (int)(ry1 / 8);
+        const int x0 = (int)(cx0 / tile_w), x1 = (int)(cx1 / tile_w), y0 = (int)(ry0 / 8), y1 = (int)(ry1 / 8);
         const uint64_t covered = (uint64_t)(x1 - x0 + 1) * (uint64_t)(y1 - y0 + 1);
         if (covered == (uint64_t)n_tiles && n_tiles > 1) {  // the whole screen
             if (global.size() >= kMaxGlobal) return RT_OK;
@@ -621,6 +626,7 @@ int build_screen_tiles(rt_context* c, hipStream_t stream) {
     c->tiles.tile_start = c->d_tile_start;
     c->tiles.entries = c->d_tile_entries;
     c->tiles.tiles_x = tx;
+    c->tiles.col_shift = col_shift;
     c->tiles.global_begin = (uint32_t)total;
     c->tiles.n_global = (uint32_t)global.size();
     c->tiles.enabled = 1u;

@@ -75,7 +75,8 @@ __device__ __forceinline__ T table_at(const T* __restrict__ base, uint32_t index
 struct ScreenTiles {
     const uint32_t* __restrict__ tile_start;  // tiles_x * tiles_y + 1 offsets
     const uint32_t* __restrict__ entries;     // object indices, ascending inside a tile
-    uint32_t tiles_x;                         // tiles are 64 pixels wide, 8 rows tall
+    uint32_t tiles_x;                         // tiles are 8 rows tall and 1 << col_shift pixels wide:
+    uint32_t col_shift;                       //   3 (8 x 8, exactly a wave's block when work-items walk 8 x 8 blocks) or 6 (64 x 8: a wave is 64 pixels of a row)
     uint32_t global_begin, n_global;          // entries[global_begin ..): objects whose projection is the whole screen
     uint32_t enabled;
 };

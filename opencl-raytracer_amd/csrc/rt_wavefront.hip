@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void wf_trace_primary_tiles(const WfParams wk)
     const uint64_t g = global_ray_of(p, i);
     const Ray ray = primary_ray(p, g);
     const uint32_t row = (uint32_t)g / p.width, col = (uint32_t)g - row * p.width;
-    const uint32_t tile = (row >> 3) * w.tiles.tiles_x + (col >> 6);
+    const uint32_t tile = (row >> 3) * w.tiles.tiles_x + (col >> w.tiles.col_shift);
     const uint32_t first = __builtin_amdgcn_readfirstlane(tile);
     float T = kMaxFloat;
     int idx = -1;
