@@ -638,21 +638,30 @@ __device__ __forceinline__ float specular_power(float rDotV, float shininess) {
     return powf(rDotV, e);
 }
 
+// the shadow ray of light L from the point (px, py, pz), and the normalised light vector (shade_and_reflect_kernel.cl:195-205).
+// One function for everybody who needs that ray: the light loop, and the trace kernels that REBUILD it from the stored
+// hit point instead of reading a stored copy (rt_wavefront.hip) - same statements, same bits.
+template <bool FUSED>
+__device__ __forceinline__ void shadow_ray_to(const LightRec& L, float px, float py, float pz, Ray& shadow, float& nlx, float& nly, float& nlz) {
+    float lx, ly, lz;
+    if (L.position.w != 0) { lx = L.position.x - px; ly = L.position.y - py; lz = L.position.z - pz; }
+    else { lx = -L.position.x; ly = -L.position.y; lz = -L.position.z; }
+    nlx = lx; nly = ly; nlz = lz;
+    normalize3(nlx, nly, nlz);
+    shadow.sx = fma_<FUSED>(nlx, 0.01f, px);
+    shadow.sy = fma_<FUSED>(nly, 0.01f, py);
+    shadow.sz = fma_<FUSED>(nlz, 0.01f, pz);
+    shadow.sw = fma_<FUSED>(0.0f, 0.01f, 1.0f);
+    shadow.dx = lx; shadow.dy = ly; shadow.dz = lz; shadow.dw = 0.0f;
+}
+
 // everything of one light-loop iteration that does not depend on the shadow test
 // (shade_and_reflect_kernel.cl:194-224)
 template <bool FUSED>
 __device__ __forceinline__ void light_geometry(const LightRec& L, const HitRec& h, float nvx, float nvy, float nvz,
                                                float vvx, float vvy, float vvz, LightGeom& g) {
-    float lx, ly, lz;
-    if (L.position.w != 0) { lx = L.position.x - h.px; ly = L.position.y - h.py; lz = L.position.z - h.pz; }
-    else { lx = -L.position.x; ly = -L.position.y; lz = -L.position.z; }
-    float nlx = lx, nly = ly, nlz = lz;
-    normalize3(nlx, nly, nlz);
-    g.shadow.sx = fma_<FUSED>(nlx, 0.01f, h.px);
-    g.shadow.sy = fma_<FUSED>(nly, 0.01f, h.py);
-    g.shadow.sz = fma_<FUSED>(nlz, 0.01f, h.pz);
-    g.shadow.sw = fma_<FUSED>(0.0f, 0.01f, 1.0f);
-    g.shadow.dx = lx; g.shadow.dy = ly; g.shadow.dz = lz; g.shadow.dw = 0.0f;
+    float nlx, nly, nlz;
+    shadow_ray_to<FUSED>(L, h.px, h.py, h.pz, g.shadow, nlx, nly, nlz);
     g.nlx = nlx; g.nly = nly; g.nlz = nlz;
     g.nDotL = dot3(nvx, nvy, nvz, nlx, nly, nlz);
     const float kk = dot3(-nlx, -nly, -nlz, nvx, nvy, nvz) * -2.0f;

@@ -166,6 +166,22 @@ __device__ __forceinline__ void load_closest_result(const WfParams& w, uint64_t 
     idx = (int)__float_as_uint(r.y);
 }
 
+// The shadow ray a pixel has in flight on the grid path, rebuilt from what emit_shadow left in the pixel's state: the hit
+// point (F_PX block) and the light (the phase word's light index; `last_light` = the queue entry says it is the light of
+// the light tiles, and the phase word is not read). Bit for bit the ray emit_shadow computed: same function, same inputs.
+__device__ __forceinline__ bool shadow_rays_rebuilt(const WfParams& w) {
+    return w.grid.enabled && !w.rp.scene.literal && !w.grid.has_triangles;
+}
+template <bool FUSED>
+__device__ __forceinline__ Ray shadow_of_pixel(const WfParams& w, uint64_t i, bool last_light, uint32_t& li) {
+    const float4 hp = load_block(w, F_PX, i);
+    li = last_light ? w.ltiles.light : (U(w, F_PHASE, i) >> kPhaseLightShift);
+    Ray ray;
+    float nlx, nly, nlz;
+    shadow_ray_to<FUSED>(w.rp.scene.lights[li], hp.x, hp.y, hp.z, ray, nlx, nly, nlz);
+    return ray;
+}
+
 // append pixel i to a queue (wave-aggregated by the compiler: one atomic per wave per call site)
 __device__ __forceinline__ void push(uint32_t* queue, uint32_t* counter, uint64_t i) {
     const uint32_t slot = atomicAdd(counter, 1u);
@@ -181,8 +197,9 @@ __device__ __forceinline__ void push(uint32_t* queue, uint32_t* counter, uint64_
 constexpr int kResumeThreads = RT_RESUME_THREADS;
 constexpr uint32_t kQueueAlsoShadow = 0x80000000u;  // flag on a closest-queue entry (pixel ids are < 2^31: launch_wavefront checks)
 constexpr uint32_t kQueuePixel = 0x7fffffffu;
+constexpr uint32_t kQueueLastLight = 0x80000000u;  // flag on a shadow-queue entry: the ray goes to the light of the light tiles
 __device__ __forceinline__ void block_push(bool want_closest, bool want_any, uint32_t id, uint32_t* __restrict__ q_closest,
-                                           uint32_t* __restrict__ q_any, uint32_t* __restrict__ counts) {
+                                           uint32_t* __restrict__ q_any, uint32_t* __restrict__ counts, uint32_t any_flag = 0u) {
     __shared__ uint32_t s_cnt[2][kResumeThreads / 64];
     __shared__ uint32_t s_base[2];
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
@@ -200,7 +217,7 @@ __device__ __forceinline__ void block_push(bool want_closest, bool want_any, uin
     // a pixel that queues a shadow ray AND a reflection ray sits in both queues and is resumed from its shadow entry: its
     // closest-queue entry says so in its top bit, so that wf_resume can drop it without touching the pixel's state
     if (want_closest) q_closest[s_base[0] + s_cnt[0][wave] + (uint32_t)__popcll(bc & below)] = want_any ? (id | kQueueAlsoShadow) : id;
-    if (want_any) q_any[s_base[1] + s_cnt[1][wave] + (uint32_t)__popcll(ba & below)] = id;
+    if (want_any) q_any[s_base[1] + s_cnt[1][wave] + (uint32_t)__popcll(ba & below)] = id | any_flag;
 }
 
 __device__ __forceinline__ unsigned long long wave_sum64(unsigned long long v) {
@@ -483,9 +500,18 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             if (STATS && lane == 0u) ++s_refill;
             if (st == 0 && mine < seg_end) {
                 if (STATS) ++s_rays;
-                pix = (!ANY && w.identity_queue) ? mine : (queue[mine] & kQueuePixel);
-                ray = ANY ? load_ray(w, pix, kSlotShadow) : closest_ray(w, pix, w.first_round != 0u);
-                const uint32_t ray_light = __float_as_uint(ray.dw);  // shadow rays: the light they go to (emit_shadow)
+                const uint32_t entry = (!ANY && w.identity_queue) ? mine : queue[mine];
+                pix = (!ANY && w.identity_queue) ? mine : (entry & kQueuePixel);
+                uint32_t ray_light;  // shadow rays: the light they go to; reflection rays: begin_shade_lit's note (the object they leave)
+                if (ANY && !TRI) {
+                    ray = shadow_of_pixel<FUSED>(w, pix, (entry & kQueueLastLight) != 0u, ray_light);
+                } else if (ANY) {
+                    ray = load_ray(w, pix, kSlotShadow);
+                    ray_light = __float_as_uint(ray.dw);
+                } else {
+                    ray = closest_ray(w, pix, w.first_round != 0u);
+                    ray_light = __float_as_uint(ray.dw);
+                }
                 ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
                 in_lt = false;
                 // reflection rays: the object the ray leaves has had its exact test already (begin_shade_lit)
@@ -762,6 +788,7 @@ struct Ctx {
     float4 pre_hit, pre_res, pre_acc;
     Ray pre_ray0;
     unsigned long long tests = 0;  // exact object tests run by the step itself (last_light_blocked)
+    uint32_t any_flag = 0;         // kQueueLastLight on the pixel's shadow-queue entry (emit_shadow)
 };
 
 template <int KERNEL>
@@ -780,8 +807,16 @@ __device__ __forceinline__ void emit_shadow(Ctx& c, const HitRec& h, uint32_t li
     normalize3(vvx, vvy, vvz);
     LightGeom g;
     light_geometry<FUSED>(S.lights[li], h, nvx, nvy, nvz, vvx, vvy, vvz, g);
-    g.shadow.dw = __uint_as_float(li);  // direction.w of a shadow ray is 0 and no any-hit test reads the slot: it carries the light index to the trace kernel (light tiles)
-    store_ray(c.w, c.i, g.shadow, kSlotShadow);
+    // Through the grid the shadow ray is not stored: the trace kernels rebuild it from the hit point (shadow_of_pixel) - 32 bytes
+    // per shadow ray that wf_resume does not write and 16 that the walk does not read. The brute-force / literal trace kernels
+    // read the stored record; direction.w (0 for a shadow ray, read by no any-hit test) carries the light index there.
+    // (Not for meshes: their shadow walk is the heavier kernel, and the rebuild cost cfg5 58.5 -> 59.8 ms; cfg4: 16.74 -> 16.38.)
+    if (shadow_rays_rebuilt(c.w)) {
+        c.any_flag = (c.w.ltiles.enabled && li == c.w.ltiles.light) ? kQueueLastLight : 0u;
+    } else {
+        g.shadow.dw = __uint_as_float(li);
+        store_ray(c.w, c.i, g.shadow, kSlotShadow);
+    }
     if (new_hit) store_block(c.w, F_PX, c.i, make_float4(h.px, h.py, h.pz, __uint_as_float((uint32_t)h.index)));
     store_block(c.w, F_NX, c.i, make_float4(h.nx, h.ny, h.nz, __uint_as_float(phase | (li << kPhaseLightShift))));
     c.want_any = true;
@@ -1211,7 +1246,7 @@ __global__ __launch_bounds__(kResumeThreads) __attribute__((amdgpu_waves_per_eu(
         c.i = entry & kQueuePixel;
         if (!duplicate_entry(w, t, entry)) resume_pixel<KERNEL, FUSED>(c);
     }
-    block_push(c.want_closest, c.want_any, (uint32_t)c.i, w.q_closest, w.q_any, w.counts);
+    block_push(c.want_closest, c.want_any, (uint32_t)c.i, w.q_closest, w.q_any, w.counts, c.any_flag);
     if (w.count_rays) add_ray_counters(w, c);
 }
 
@@ -1238,8 +1273,15 @@ __global__ __launch_bounds__(256) void wf_finish(const WfParams wk) {
             bool do_any = !(t < w.n_prev_closest);
             for (;;) {
                 if (do_any) {
-                    const Ray ray = load_ray(w, c.i, kSlotShadow);
-                    const bool blocked = (w.ltiles.enabled && __float_as_uint(ray.dw) == w.ltiles.light)
+                    uint32_t li;
+                    Ray ray;
+                    if (shadow_rays_rebuilt(w)) {
+                        ray = shadow_of_pixel<FUSED>(w, c.i, false, li);
+                    } else {
+                        ray = load_ray(w, c.i, kSlotShadow);
+                        li = __float_as_uint(ray.dw);
+                    }
+                    const bool blocked = (w.ltiles.enabled && li == w.ltiles.light)
                                              ? last_light_blocked<FUSED>(w, ray, tested)   // (the walk's choice: trace_segment)
                                              : any_hit_grid<FUSED>(w.grid, w.rp.scene, ray, tested);
                     U(w, F_RES_ANY, c.i) = blocked ? 0u : 1u;
