@@ -79,6 +79,7 @@ struct rt_context {
     uint32_t* d_tile_entries = nullptr;
     rt::ScreenTiles tiles = {};
     bool tiles_dirty = true;
+    uint32_t tiles_built_for = 0;           // the tile width (as a shift) the last build was asked for
     bool has_triangles = false;             // type-2 records (extension): only the grid path knows them
     int nan_winner = -1;                    // the last sphere / box of the scene decides what a NaN ray ends with (rt_device.h)
     bool nan_winner_sphere = false;
@@ -530,9 +531,16 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
         if (rc) return rc;
         // a first-round wave is an 8 x 8 block of pixels (work-items in tile order) or 64 pixels of one row: the tile lists follow
         const uint32_t col_shift = p.wf_tile_order ? 3u : 6u;
-        if (c->tiles_dirty || (c->tiles.enabled && c->tiles.col_shift != col_shift)) {
+        if (c->tiles_dirty || c->tiles_built_for != col_shift) {
             rc = build_screen_tiles(c, stream, col_shift);
             if (rc) return rc;
+            // objects that cover much of the screen can exceed the pair budget at 8 x 8: the 64 x 8 tiles of round 1 serve an
+            // 8 x 8 wave as well (its block lies inside one of them)
+            if (!c->tiles.enabled && col_shift == 3u) {
+                rc = build_screen_tiles(c, stream, 6u);
+                if (rc) return rc;
+            }
+            c->tiles_built_for = col_shift;
         }
         c->wf.tiles = c->tiles;
     }

@@ -543,6 +543,36 @@ def test_randomised_configurations_vs_oracle(seed, restatement):
         assert compare_frames(out, want["out"]) <= RGB_ATOL
 
 
+def test_screen_tiles_fall_back_to_wide_tiles_for_objects_that_cover_the_screen():
+    """Thirty spheres that each cover ~15 % of a 512 x 512 frame: binned into 8 x 8-pixel screen tiles they exceed the
+    (object, tile) budget, binned into 64 x 8 tiles they do not - the first round must still go through tile lists (the
+    wide ones) and give the brute-force picture; the same scene in a frame whose height is not a multiple of 8 walks the
+    frame row by row (64 x 8 tiles from the start)."""
+    from helpers import instance
+    rng = np.random.default_rng(4242)
+    objs = []
+    for k in range(30):
+        mat = R.Material((.2, .3, .4), (.5, .5, .5), (.4, .4, .4), absorption=float(rng.choice([0.3, 0.7])), reflection=0.5, shininess=5.0)
+        pos = (float(rng.uniform(-14, 14)), float(rng.uniform(-14, 14)), float(rng.uniform(-60, -30)))
+        mv, inv = instance(pos, None, (9.0, 9.0, 9.0))
+        objs.append(R.make_object(R.SPHERE, mat, mv, inv))
+    objs = R.objects_array(objs)
+    lights = R.lights_array([R.make_light(R.LightProperties((.2, .2, .2), (.6, .6, .6), (.5, .5, .5)), position=(30.0, 40.0, 10.0, 1.0))])
+    for W, H in ((512, 512), (512, 508)):
+        z = float(camera.camera_z(H))
+        res = {}
+        for grid in (True, False):
+            with hip(objs, lights, None, 3, camera=(W, H, z), grid=grid, path="wavefront") as rt:
+                out = rt.Render()
+                t, idx = rt.render_aux()
+                st = rt.count_rays()
+                res[grid] = (out.view(np.uint32).copy(), t.view(np.uint32).copy(), idx.copy(), st.rays_reference, st.hit_pixels, st.object_tests)
+        a, b = res[True], res[False]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3:5] == b[3:5]
+        assert a[4] > W * H // 4          # the spheres do cover a good part of the frame
+        assert a[5] < b[5] // 2           # ... and the grid path went through lists, not through every object
+
+
 def test_config4_full_frame_grid_equals_brute_force():
     """BASELINE configs[3] at full size (100 000 spheres, 32 lights, 4096 x 4096, depth 3): the default (grid) path
     and the brute-force path - which tests every object for every one of the 109 M rays - produce the same 16.7 M
