@@ -311,6 +311,26 @@ def main():
     def step():
         return rt.Render()
 
+    pipeline_note = None
+    if pipeline:
+        # self-check on THIS node before anything is timed: the pipelined exchange must deliver the frame the synchronous
+        # exchange delivers, bit for bit (both slots exercised); otherwise time the synchronous path and say so
+        ref = rt.render_synchronous()
+        ok = 1
+        for _ in range(3):
+            f = step()
+            if rank == 0 and not torch.equal(f, ref):
+                ok = 0
+        torch.cuda.synchronize(device)
+        flag = torch.tensor([ok], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) != 1:
+            rt.gatherer.drain()
+            rt.gatherer.pipeline = False
+            rt.gatherer.k = 0
+            pipeline = False
+            pipeline_note = "the pipelined exchange disagreed with the synchronous one in the self-check: timed synchronously"
+        del ref
     for _ in range(warmup):
         step()
     torch.cuda.synchronize(device)
@@ -357,7 +377,8 @@ def main():
             "config": {"workload": desc, "width": frame_w, "height": frame_h, "objects": int(len(objs)),
                        "lights": int(len(lights)), "kernel": kernel, "depth": depth, "primary_rays": ray_source,
                        "partition": (f"row-tiles of {args.tile_rows} rows, interleaved over {world} rank(s), gather to rank 0"
-                                     + (", frame k's exchange overlapped with frame k+1's render" if pipeline else ""))
+                                     + (", frame k's exchange overlapped with frame k+1's render (self-checked against the synchronous exchange)" if pipeline else "")
+                                     + (f" [{pipeline_note}]" if pipeline_note else ""))
                        if world > 1 else "single GPU", "arithmetic": "fused (fma where the OpenCL front-end marks fmuladd)",
                        "literal": bool(args.literal)},
             # `value` counts the rays the REFERENCE semantics trace for the frame (R_ref); what this backend

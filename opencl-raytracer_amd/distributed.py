@@ -214,6 +214,22 @@ class ShardedHIPRaytracer:
         self.rt.render_device(g.local.data_ptr(), stream.cuda_stream)
         return g.exchange_pipelined()
 
+    def render_synchronous(self):
+        """One frame through the synchronous path (render, then exchange, then assembly, all on the caller's stream),
+        whatever mode the object is in; returns a COPY of the frame on rank 0. For self-checks of the pipelined mode."""
+        g = self.gatherer
+        g.drain()
+        torch.cuda.synchronize(self.device)
+        saved, k0 = g.pipeline, g.k
+        g.pipeline, g.k = False, 0
+        try:
+            self.render_local()
+            frame = g.gather()
+            torch.cuda.synchronize(self.device)
+            return None if frame is None else frame.clone()
+        finally:
+            g.pipeline, g.k = saved, k0 + (k0 & 1)   # (continue with slot 0: nothing is in flight)
+
     def close(self):
         self.gatherer.drain()
         self.rt.close()
