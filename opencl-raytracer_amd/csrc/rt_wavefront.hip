@@ -397,6 +397,9 @@ constexpr uint32_t kTicketBase = 16;     // counts[16 ..]: closest-hit launch, c
 #ifndef RT_INLINE_LAST_SHADOW
 #define RT_INLINE_LAST_SHADOW 1  // a path's last hit tests its last-light shadow ray inside wf_resume (shade_last_light_inline)
 #endif
+#ifndef RT_FLAT_PARK
+#define RT_FLAT_PARK 1
+#endif
 #ifndef RT_CELL_INLINE
 #define RT_CELL_INLINE 1  // the persistent walk reads 32-byte cell records that hold the first entry (GridDesc::cell_rec) - range and first
                           // candidate in ONE request instead of two dependent ones: cfg4 17.5 -> 17.0 ms. Not for sparsely occupied
@@ -585,8 +588,12 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             }
             e = range.x;
             e1 = range.x + range.y;
-            if (range.y != 0u) st = 2;
-            else { advance = true; skip = range.x < skip_cap ? range.x : skip_cap; }  // empty: its offset word says how many further steps stay in empty cells
+            {   // (branch-free, like the parking logic below) an empty cell's offset word says how many further steps stay in empty cells
+                const bool occupied = range.y != 0u;
+                st = occupied ? 2 : 1;
+                advance = !occupied;
+                skip = occupied ? 0u : (range.x < skip_cap ? range.x : skip_cap);
+            }
         }
         // ---- phase B: pre-test one candidate (also for a lane that has just fetched a non-empty cell) ----
         if (st == 2) {
@@ -596,9 +603,10 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             else bound = table_at(g.entry_sphere, e);
             if (STATS) ++s_pre;
             bool pass = !misses_bounding_sphere(bound, ray, dd, g.pretest_alpha);
-            if (ANY && in_lt && aux.x > slack) {  // sorted by distance from the light: this entry and all after it lie beyond the ray's origin
-                pass = false;
-                e = e1 - 1u;
+            if (ANY) {  // light tiles: sorted by distance from the light - this entry and all after it lie beyond the ray's origin
+                const bool beyond = in_lt && aux.x > slack;
+                pass = pass && !beyond;
+                e = beyond ? e1 - 1u : e;
             }
             uint32_t k = 0u;
             if (pass) {  // the same object again (parked, or tested a cell ago)? its result is known or on its way
@@ -608,6 +616,17 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
 #endif
                 if (RT_WALK_FIRST_CELL && TRI && !(ANY && in_lt) && entered_inside(bound, ray, wk.t_enter, g.own_shrink)) pass = false;
             }
+#if RT_FLAT_PARK
+            {   // (branch-free: every nested divergent `if` costs this loop half a dozen scalar instructions of exec-mask bookkeeping)
+                const bool stall = pass && pend;   // one parking slot: wait for the exact tests
+                const bool park = pass && !pend;
+                blocked = stall;
+                pend_k = park ? k : pend_k;
+                pend = pend || park;
+                e += stall ? 0u : 1u;
+                advance = advance || (!stall && e == e1);
+            }
+#else
             if (pass && pend) {
                 blocked = true;  // one parking slot: wait for the exact tests
             } else {
@@ -615,6 +634,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 ++e;
                 if (e == e1) advance = true;
             }
+#endif
         }
         // ---- step to the next cell, or end the walk ----
         if (advance) {
