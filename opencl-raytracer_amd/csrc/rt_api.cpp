@@ -75,6 +75,8 @@ struct rt_context {
     uint2* d_lt_range = nullptr;            // light tiles (rt_grid.h: LightTiles) for the last light's shadow rays
     float4* d_lt_records = nullptr;
     rt::LightTiles light_tiles = {};
+    std::vector<float4> h_walk;             // the unified walk's records while they are being put together (rt_grid.h: GridDesc::walk_rec)
+    float4* d_walk_rec = nullptr;
     uint32_t* d_tile_start = nullptr;       // screen tiles (64 x 8 pixels) -> objects a pinhole primary ray can reach
     uint32_t* d_tile_entries = nullptr;
     rt::ScreenTiles tiles = {};
@@ -641,6 +643,78 @@ int build_screen_tiles(rt_context* c, hipStream_t stream, uint32_t col_shift) {
     return RT_OK;
 }
 
+// The unified walk's record table (rt_grid.h: GridDesc::walk_rec), host side. build_grid puts down one head per cell of
+// the grid padded by two empty cells on every side, then the 2nd, 3rd ... entries of every cell; build_light_tiles appends
+// the light tiles' entries; upload_walk_records ships the table (or drops it when it would not fit 32-bit byte offsets).
+constexpr uint32_t kWalkBorder = 2;
+inline float4 walk_sphere(const float4& es) {
+    const volatile float w = es.w;
+    const volatile float w2 = w * w;  // the fp32 product the pre-test used to form per trip
+    return make_float4(es.x, es.y, es.z, w2);
+}
+inline float4 walk_link(uint32_t object, uint32_t next, float key) {
+    float4 r;
+    std::memcpy(&r.x, &object, 4);
+    std::memcpy(&r.y, &next, 4);
+    r.z = key;
+    r.w = 0.f;
+    return r;
+}
+void build_walk_records(rt_context* c, const int dim[3], const std::vector<uint2>& ranges, const std::vector<float4>& es,
+                        const std::vector<uint32_t>& entries) {
+    c->h_walk.clear();
+    c->grid.walk_rec = nullptr;
+    c->grid.walk_cells = 0;
+    if (std::getenv("RT_NO_WALK2")) return;  // measurement knob: the round-2 walk
+    const uint64_t wnx = (uint64_t)dim[0] + 2 * kWalkBorder, wny = (uint64_t)dim[1] + 2 * kWalkBorder, wnz = (uint64_t)dim[2] + 2 * kWalkBorder;
+    const uint64_t cells = wnx * wny * wnz;
+    uint64_t overflow = 0;
+    for (const uint2& r : ranges) overflow += r.y > 1u ? r.y - 1u : 0u;
+    if ((cells + overflow) * 32ull >= 0xf0000000ull) return;
+    const float ninf = -std::numeric_limits<float>::infinity();
+    const uint32_t none = c->n_objs;
+    std::vector<float4>& rec = c->h_walk;
+    rec.assign(2 * (size_t)(cells + overflow), make_float4(0.f, 0.f, 0.f, 0.f));
+    for (size_t k = 0; k < (size_t)cells; ++k) {
+        rec[2 * k] = make_float4(0.f, 0.f, 0.f, ninf);
+        rec[2 * k + 1] = walk_link(none, 0u, ninf);
+    }
+    uint64_t next_free = cells;
+    for (int z = 0; z < dim[2]; ++z)
+        for (int y = 0; y < dim[1]; ++y)
+            for (int x = 0; x < dim[0]; ++x) {
+                const uint2 r = ranges[((size_t)z * dim[1] + y) * dim[0] + x];
+                if (r.y == 0u) continue;
+                const size_t head = (size_t)(((uint64_t)(z + kWalkBorder) * wny + (y + kWalkBorder)) * wnx + (x + kWalkBorder));
+                rec[2 * head] = walk_sphere(es[r.x]);
+                rec[2 * head + 1] = walk_link(entries[r.x], r.y > 1u ? (uint32_t)next_free : 0u, ninf);
+                for (uint32_t j = 1; j < r.y; ++j) {
+                    const size_t at = (size_t)next_free++;
+                    rec[2 * at] = walk_sphere(es[r.x + j]);
+                    rec[2 * at + 1] = walk_link(entries[r.x + j], j + 1u < r.y ? (uint32_t)next_free : 0u, ninf);
+                }
+            }
+    c->grid.walk_cells = (uint32_t)cells;
+    c->grid.walk_nx = (uint32_t)wnx;
+    c->grid.walk_nxy = (uint32_t)(wnx * wny);
+    c->grid.walk_none = none;
+}
+
+int upload_walk_records(rt_context* c) {
+    if (c->h_walk.empty() || (uint64_t)c->h_walk.size() * 16ull >= 0xfffffff0ull) {
+        std::vector<float4>().swap(c->h_walk);
+        c->grid.walk_rec = nullptr;
+        c->grid.walk_cells = 0;
+        c->light_tiles.walk_base = 0;
+        return RT_OK;
+    }
+    RT_HIP(c, hipMalloc((void**)&c->d_walk_rec, sizeof(float4) * c->h_walk.size()));
+    RT_HIP(c, hipMemcpy(c->d_walk_rec, c->h_walk.data(), sizeof(float4) * c->h_walk.size(), hipMemcpyHostToDevice));
+    c->grid.walk_rec = c->d_walk_rec;
+    std::vector<float4>().swap(c->h_walk);
+    return RT_OK;
+}
+
 // Conservative uniform grid for the large-scene trace kernels (rt_grid.h explains the margins).
 int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     c->grid = rt::GridDesc{};
@@ -890,6 +964,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
                     }
                     RT_HIP(c, hipMalloc((void**)&c->d_grid_cell_rec, sizeof(float4) * 2 * n_cells));
                     RT_HIP(c, hipMemcpy(c->d_grid_cell_rec, rec.data(), sizeof(float4) * 2 * n_cells, hipMemcpyHostToDevice));
+                    build_walk_records(c, dim, ranges, es, entries);
                 }
             }
             if (total) RT_HIP(c, hipMemcpy(c->d_grid_entries, entries.data(), sizeof(uint32_t) * total, hipMemcpyHostToDevice));
@@ -1081,6 +1156,19 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
     lt.sx = 1.f; lt.sy = 1.f; lt.sz = (float)szn;
     lt.light = li;
     lt.enabled = 1u;
+    if (!c->h_walk.empty() && total) {  // the same lists as records of the unified walk, each tile's chained to its end
+        const uint64_t base = c->h_walk.size() / 2;
+        if ((base + total) * 32ull < 0xf0000000ull) {
+            c->h_walk.resize(2 * (size_t)(base + total));
+            for (size_t t = 0; t < ranges.size(); ++t)
+                for (uint32_t j = 0; j < ranges[t].y; ++j) {
+                    const size_t k = (size_t)ranges[t].x + j;
+                    c->h_walk[2 * (base + k)] = walk_sphere(recs[2 * k]);
+                    c->h_walk[2 * (base + k) + 1] = walk_link(entries[k], j + 1u < ranges[t].y ? (uint32_t)(base + k + 1) : 0u, recs[2 * k + 1].x);
+                }
+            lt.walk_base = (uint32_t)base;
+        }
+    }
     return RT_OK;
 }
 
@@ -1182,10 +1270,14 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
             }
         }
         RT_TRY(hipMalloc((void**)&c->d_bounds, sizeof(float4) * 65));
-        if (n_objs) {
-            RT_TRY(hipMemcpy(c->d_hot, hot.data(), sizeof(rt::HotObject) * n_objs, hipMemcpyHostToDevice));
-            RT_TRY(hipMemcpy(c->d_cold, cold.data(), sizeof(rt::ColdObject) * n_objs, hipMemcpyHostToDevice));
+        {   // the spare HotObject behind the last one can never be hit (unknown type): records of the unified walk that hold
+            // no candidate point at it (GridDesc::walk_none)
+            rt::HotObject none{};
+            none.type = 0xffffffffu;
+            hot.push_back(none);
+            RT_TRY(hipMemcpy(c->d_hot, hot.data(), sizeof(rt::HotObject) * (size_t)(n_objs + 1), hipMemcpyHostToDevice));
         }
+        if (n_objs) RT_TRY(hipMemcpy(c->d_cold, cold.data(), sizeof(rt::ColdObject) * n_objs, hipMemcpyHostToDevice));
     }
     RT_TRY(hipMalloc((void**)&c->d_lights, sizeof(rt::LightRec) * (size_t)(n_lights + 1)));
     if (n_lights) RT_TRY(hipMemcpy(c->d_lights, lights, sizeof(rt::LightRec) * n_lights, hipMemcpyHostToDevice));
@@ -1240,6 +1332,8 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         rc = build_grid(c, static_cast<const rt_object_data*>(objs), n_objs);
         if (rc != RT_OK) return bail(rc);
         rc = build_light_tiles(c, static_cast<const rt_light*>(lights));
+        if (rc != RT_OK) return bail(rc);
+        rc = upload_walk_records(c);
         if (rc != RT_OK) return bail(rc);
     }
     if (c->has_triangles && (!c->grid.enabled || (flags & (RT_FLAG_LITERAL | RT_FLAG_MONOLITHIC | RT_FLAG_NO_GRID)))) {
@@ -1424,6 +1518,7 @@ void rt_destroy(rt_context* c) {
     if (c->d_tile_entries) (void)hipFree(c->d_tile_entries);
     if (c->d_lt_range) (void)hipFree(c->d_lt_range);
     if (c->d_lt_records) (void)hipFree(c->d_lt_records);
+    if (c->d_walk_rec) (void)hipFree(c->d_walk_rec);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->d_out) (void)hipFree(c->d_out);

@@ -61,6 +61,20 @@ struct GridDesc {
     float own_shrink;      // first-cell rule (entered_inside): how much smaller than an entry's |w| the ball is taken (usually 0)
     uint32_t has_triangles;  // the scene holds type-2 records (selects the kernel variants that know them)
     uint32_t enabled;
+    // The unified walk (rt_wavefront.hip: walk_segment; scenes without triangles). ONE table of 32-byte records
+    //   [0] {cx, cy, cz, w^2}   bounding sphere of a candidate (centre, SQUARED pre-test radius; -inf: no candidate here)
+    //   [1] {object, next, key, 0}   next = index of the record to look at after this one; 0 = the list ends, step to the next cell
+    // indexed as: [0, walk_cells) one head per cell of the grid PADDED by two empty cells on every side (strides walk_nx,
+    // walk_nxy; cell (ix, iy, iz) of the grid proper is head ((iz + 2) walk_ny + iy + 2) walk_nx + ix + 2) - the head holds the
+    // cell's first entry, so range and first candidate still arrive with one request; then the 2nd, 3rd ... entries of every
+    // cell, consecutive; then the light tiles' entries (LightTiles::walk_base; key = the entry's distance key, -inf elsewhere).
+    // Every trip of a walking lane is the same: fetch the record under its cursor, pre-test it, move the cursor. The empty
+    // border replaces the per-axis step budgets: a walk ends when it passes its exit parameter (+ a quarter step), which
+    // it does inside the border. A record without a candidate points at object `walk_none`, a never-hit dummy behind the
+    // last HotObject, so that even a pre-test that lets it through (overflow to NaN) does no harm.
+    const float4* __restrict__ walk_rec;
+    uint32_t walk_cells, walk_nx, walk_nxy;
+    uint32_t walk_none;
 };
 
 // Element `index` of a read-only table smaller than 4 GiB (build_grid / build_light_tiles refuse larger ones): the byte
@@ -102,6 +116,7 @@ struct LightTiles {
     float sx, sy, sz;                          // ... times this sign
     uint32_t light;                            // index of the light the structure is for
     uint32_t enabled;
+    uint32_t walk_base;                        // entry e of a tile = record walk_base + e of GridDesc::walk_rec (0: not built)
 };
 
 // tile of the ray whose ORIGIN is `s` (any point of the line through the light does): false = no object in that direction
@@ -230,6 +245,7 @@ struct Walk {
     float tx, ty, tz;      // ray parameter at which the walk crosses the next x / y / z cell wall
     float dtx, dty, dtz;   // parameter advance per cell
     float t_enter;         // parameter at which the current cell was entered
+    float t_exit;          // parameter at which the ray leaves the grid box (or reaches t_limit)
     bool alive;
 };
 
@@ -292,6 +308,7 @@ __device__ __forceinline__ Walk walk_begin(const GridDesc& g, const Ray& ray, fl
     w.dty = dy != 0.f ? g.cell * __builtin_fabsf(invy) : big;
     w.dtz = dz != 0.f ? g.cell * __builtin_fabsf(invz) : big;
     w.t_enter = t0;
+    w.t_exit = t1;
     w.alive = true;
     return w;
 }

@@ -710,6 +710,282 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRI ? RT_WA
     if (STATS && tested) atomicAdd(&w.rp.counters->tests, tested);
 }
 
+// ---- grid traversal, unified form (scenes without triangles) -----------------------------------------------------------
+// What the profile of trace_segment said (round 2: ~170 vector + ~130 scalar instructions per wave-trip with 32 of 64 lanes
+// active): the trip count is near its floor, the cost of a trip is not - a lane is EITHER fetching a cell OR pre-testing an
+// entry OR stepping, every state is a divergent branch, and half the lanes sit out each of them. Here every walking lane
+// does the same thing in every trip: fetch the 32-byte record under its cursor (GridDesc::walk_rec: cell heads, the further
+// entries of a cell and the light tiles' entries share one format), pre-test it, move the cursor along `next` - and, when
+// the list ends, to the next cell of a DDA whose step is computed by every lane in every trip and taken by select. No
+// per-axis step budgets: the record table carries two empty cells around the grid, and a walk ends once it passes the
+// parameter at which the ray leaves the grid box plus a quarter of its smallest cell step (walk2_limits), which happens
+// inside that border. Same cells in the same order, same pre-test, same exact tests, same order-free update as
+// trace_segment -> same results; the tests compare both with the brute-force path bit for bit.
+#ifndef RT_WALK2_WAVES
+#define RT_WALK2_WAVES 6
+#endif
+#ifndef RT_WALK2_REFILL_MIN
+#define RT_WALK2_REFILL_MIN RT_REFILL_MIN
+#endif
+#ifndef RT_WALK2_DEFER_PENDING
+#define RT_WALK2_DEFER_PENDING RT_DEFER_PENDING
+#endif
+
+// (the pre-test of rt_grid.h with the squared radius taken from the record; w2 = -inf: never passes)
+__device__ __forceinline__ bool misses_bounding_sphere2(const float4 s, float sx, float sy, float sz, float dx, float dy, float dz,
+                                                        float dd, float alpha) {
+    const float ox = s.x - sx, oy = s.y - sy, oz = s.z - sz;
+    const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float od = __builtin_fmaf(oz, dz, __builtin_fmaf(oy, dy, ox * dx));
+    const float c = oo - s.w;
+    const float disc = __builtin_fmaf(od, od, -(dd * __builtin_fmaf(-alpha, oo, c)));
+    return disc < 0.f || (od < 0.f && c > 1.0e-5f * oo);
+}
+
+template <bool FUSED, bool ANY, bool STATS>
+__device__ __forceinline__ void walk_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue,
+                                             uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr,
+                                             unsigned long long& tested) {
+    const uint32_t lane = threadIdx.x & 63u;
+    // runs and tickets: as trace_segment
+    uint32_t seg = kSegment;
+    while (seg > 64u && n_queue < 2u * n_waves * seg) seg >>= 1;
+    const uint32_t n_runs = (n_queue + seg - 1u) / seg;
+    const bool dynamic = n_runs > n_waves;
+    uint32_t next = 0, seg_end = 0;
+    uint32_t region = 0, regions_tried = 0;
+    if (kTicketRegions > 1u) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        region = (xcc & 0xfu) % kTicketRegions;
+    }
+    auto grab = [&]() -> bool {
+        for (;;) {
+            const uint32_t lo = (uint32_t)(((uint64_t)n_runs * region) / kTicketRegions);
+            const uint32_t hi = (uint32_t)(((uint64_t)n_runs * (region + 1u)) / kTicketRegions);
+            uint32_t r = 0;
+            if (lane == 0u) r = atomicAdd(run_ctr + region * kTicketStride, 1u);
+            r = __builtin_amdgcn_readfirstlane(r) + lo;
+            if (r < hi) {
+                next = r * seg;
+                seg_end = (n_queue - next < seg) ? n_queue : next + seg;
+                return true;
+            }
+            if (++regions_tried >= kTicketRegions) return false;
+            region = (region + 1u == kTicketRegions) ? 0u : region + 1u;
+        }
+    };
+    bool more = dynamic;
+    if (dynamic) {
+        if (!grab()) return;
+    } else {
+        if (wave >= n_runs) return;
+        next = wave * seg;
+        seg_end = (n_queue - next < seg) ? n_queue : next + seg;
+    }
+    const GridDesc& g = w.grid;
+    const HotObject* __restrict__ hot = w.rp.scene.hot;
+    const float4* __restrict__ rec = g.walk_rec;
+
+    unsigned long long s_rays = 0, s_trips = 0, s_live = 0, s_fetch = 0, s_pre = 0, s_flush = 0, s_refill = 0;  // STATS only
+    bool alive = false;   // the lane holds a ray ...
+    bool over = false;    // ... whose walk has ended (it may still wait for its parked exact test)
+    uint32_t pix = 0;
+    float rsx = 0.f, rsy = 0.f, rsz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, dd = 0.f;
+    uint32_t cursor = 0, cell = 0;            // record to look at next; head record of the current cell
+    float tx = 0.f, ty = 0.f, tz = 0.f, dtx = 0.f, dty = 0.f, dtz = 0.f;
+    int stx = 0, sty = 0, stz = 0;
+    float T = kMaxFloat, limit = 0.f, t_stop = 0.f;
+    float slack = 0.f;                        // closest: walk slack past the best hit; shadow rays: the light tile's cut (+inf: none)
+    int idx = -1;
+    bool cur_sphere = false;
+    bool pend = false;
+    uint32_t pend_k = 0, done_k = 0xffffffffu;
+
+    for (;;) {
+        // ---- hand out rays to idle lanes ----
+        const unsigned long long idle = __ballot(!alive);
+        if (next < seg_end && ((uint32_t)__popcll(idle) >= (uint32_t)RT_WALK2_REFILL_MIN || idle == ~0ull)) {
+            const uint32_t mine = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (STATS && lane == 0u) ++s_refill;
+            if (!alive && mine < seg_end) {
+                if (STATS) ++s_rays;
+                const uint32_t entry = (!ANY && w.identity_queue) ? mine : queue[mine];
+                pix = (!ANY && w.identity_queue) ? mine : (entry & kQueuePixel);
+                uint32_t note;  // shadow rays: the light they go to; reflection rays: begin_shade_lit's note (the object they leave)
+                Ray ray;
+                if (ANY) {
+                    ray = shadow_of_pixel<FUSED>(w, pix, (entry & kQueueLastLight) != 0u, note);
+                } else {
+                    ray = closest_ray(w, pix, w.first_round != 0u);
+                    note = __float_as_uint(ray.dw);
+                }
+                ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
+                rsx = ray.sx; rsy = ray.sy; rsz = ray.sz; rdx = ray.dx; rdy = ray.dy; rdz = ray.dz;
+                T = kMaxFloat; idx = -1; cur_sphere = false; pend = false; over = false;
+                done_k = (!ANY && w.first_round == 0u) ? note : 0xffffffffu;
+                dd = rdx * rdx + rdy * rdy + rdz * rdz;
+                const float slk = dd > 0.f ? kWalkSlackCells * g.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
+                bool start = false;   // a walk begins
+                bool brute = false;   // not this walk's kind of ray: every object is tested here and now
+                if (ANY && w.ltiles.enabled && note == w.ltiles.light) {
+                    // the last light's shadow ray: one tile of the light's own perspective holds every object it can meet
+                    uint32_t tile;
+                    float cut;
+                    const float chk = ((rsx + rsy) + rsz) + ((rdx + rdy) + rdz);
+                    if (chk == chk && light_tile_of(w.ltiles, rsx, rsy, rsz, tile, cut)) {
+                        const uint2 range = table_at(w.ltiles.tile_range, tile);
+                        if (range.y != 0u) {
+                            start = true;
+                            cursor = w.ltiles.walk_base + range.x;
+                            slack = cut;        // how far from the light an occluder can start
+                            limit = -1.0f;      // the list is all there is: its end ends the walk (0 > -1)
+                            tx = ty = tz = 0.f; dtx = dty = dtz = 0.f;
+                            stx = sty = stz = 0; cell = 0u;
+                        }
+                    }
+                } else {
+                    const Walk w0 = walk_begin(g, ray, ANY ? 1.0f + slk : 3.0e38f);  // (a ray with a NaN in it: not alive)
+                    if (w0.alive) {
+                        // The unified walk is made for rays whose cell steps are exact enough to end inside the table's
+                        // two-cell border: a direction of sane magnitude and an origin in (or near) the grid box - every
+                        // ray a frame produces by itself. Anything else (caller-made primary rays from far away, with
+                        // directions of 1e20 ...) tests every object instead: rare, slow, and the same result.
+                        const float dmin = __builtin_fminf(__builtin_fminf(w0.dtx, w0.dty), w0.dtz);
+                        const bool tame = dd > 1.0e-30f && dd < 1.0e30f && w0.t_enter <= 4096.f * dmin;
+                        brute = !tame;
+                        start = tame;
+                        cell = ((uint32_t)(w0.iz + 2) * g.walk_nxy) + ((uint32_t)(w0.iy + 2) * g.walk_nx) + (uint32_t)(w0.ix + 2);
+                        cursor = cell;
+                        tx = w0.tx; ty = w0.ty; tz = w0.tz; dtx = w0.dtx; dty = w0.dty; dtz = w0.dtz;
+                        stx = w0.stepx > 0 ? 1 : -1;
+                        sty = w0.stepy > 0 ? (int)g.walk_nx : -(int)g.walk_nx;
+                        stz = w0.stepz > 0 ? (int)g.walk_nxy : -(int)g.walk_nxy;
+                        // past this parameter the ray is outside the grid box (t_exit), by at most a quarter of a cell step along
+                        // any axis: still inside the border, no further cell of the box ahead
+                        t_stop = __builtin_fminf(w0.t_exit + 0.25f * dmin, 3.0e38f);
+                        limit = t_stop;  // (closest: T is +MAX until something is hit; shadow: t_exit <= 1 + slack already)
+                        slack = ANY ? __builtin_inff() : slk;
+                    }
+                }
+                bool done = false;    // shadow rays: occluded already
+                {   // objects every ray must test (usually none); a ray the walk is not made for tests them all
+                    const uint32_t n_loop = brute ? w.rp.scene.n_objs : g.n_always;
+                    for (uint32_t a = 0; a < n_loop && !done; ++a) {
+                        const int k = brute ? (int)a : (int)g.always[a];
+                        float t;
+                        bool sphere;
+                        const bool cand = lane_candidate<FUSED, true, false>(hot + k, ray, t, sphere);
+                        if (STATS) ++tested;
+                        if (ANY) done = cand && !(t >= 1.f);
+                        else if (cand) closest_take(t, k, sphere, T, idx, cur_sphere);
+                    }
+                    if (!ANY) limit = __builtin_fminf(T + slack, t_stop);
+                }
+                if (done || !start) {  // occluded by an always-object, no cell / light tile to look at, or everything tested already
+                    if (ANY) U(w, F_RES_ANY, pix) = (done || nan_shadow_blocked(w.rp.scene, ray)) ? 0u : 1u;
+                    else store_closest_result(w, pix, T, idx);
+                } else {
+                    alive = true;
+                }
+            }
+            next += (uint32_t)__popcll(idle);
+            if (next >= seg_end && more) more = grab();  // on to another run, if any is left
+        }
+        const unsigned long long live = __ballot(alive);
+        if (live == 0ull) {
+            if (next >= seg_end) break;
+            continue;
+        }
+        // ---- one trip: the record under the cursor ----
+        const bool walking = alive && !over;
+        bool stall = false;
+        if (STATS) { if (lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); } if (walking) { ++s_pre; if (cursor < g.walk_cells) ++s_fetch; } }
+        if (walking) {
+            const float4 a = table_at(rec, 2u * cursor);
+            const float4 b = table_at(rec, 2u * cursor + 1u);
+            const uint32_t k = __float_as_uint(b.x), nxt = __float_as_uint(b.y);
+            bool pass = !misses_bounding_sphere2(a, rsx, rsy, rsz, rdx, rdy, rdz, dd, g.pretest_alpha);
+            bool beyond = false;
+            if (ANY) {  // light tiles: sorted by distance from the light - this entry and all after it lie beyond the ray's origin
+                beyond = b.z > slack;
+                pass = pass && !beyond;
+            }
+            // the same object again (parked, or tested a cell ago)? its result is known or on its way
+            pass = pass && (k != done_k) && !(pend && k == pend_k);
+            stall = pass && pend;               // one parking slot: wait for the exact tests, look at this record again
+            const bool park = pass && !pend;
+            pend_k = park ? k : pend_k;
+            pend = pend || park;
+            const bool adv = !stall && nxt == 0u;  // the list ends here: on to the next cell
+            // the DDA step, computed by every lane, taken by those that advance (ties: x before y before z, as walk_next)
+            const float tmin = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+            const bool ax = (tx <= ty) && (tx <= tz);
+            const bool ay = !ax && (ty <= tz);
+            const bool az = !ax && !ay;
+            tx += (adv && ax) ? dtx : 0.f;
+            ty += (adv && ay) ? dty : 0.f;
+            tz += (adv && az) ? dtz : 0.f;
+            const int step = ax ? stx : (ay ? sty : stz);
+            cell += adv ? (uint32_t)step : 0u;
+            over = (adv && tmin > limit) || beyond;
+            cursor = stall ? cursor : (adv ? cell : nxt);
+        }
+        // ---- the exact tests, when enough lanes wait for them ----
+        const unsigned long long pending = __ballot(pend);
+        if (pending != 0ull) {
+            const unsigned long long stuck = __ballot(pend && (stall || over));
+            const uint32_t n_live = (uint32_t)__popcll(live);
+            if ((uint32_t)__popcll(pending) >= (uint32_t)RT_WALK2_DEFER_PENDING ||
+                ((uint32_t)__popcll(stuck) << RT_DEFER_STUCK_SHIFT) >= n_live) {
+                if (STATS && lane == 0u) ++s_flush;
+                if (pend) {
+                    float t;
+                    bool sphere;
+                    const Ray ray = {rsx, rsy, rsz, 1.0f, rdx, rdy, rdz, 0.0f};
+                    const bool cand = lane_candidate<FUSED, true, false>(hot + pend_k, ray, t, sphere);
+                    if (STATS) ++tested;
+                    pend = false;
+                    done_k = pend_k;
+                    if (ANY) {
+                        if (cand && !(t >= 1.f)) { U(w, F_RES_ANY, pix) = 0u; alive = false; }
+                    } else if (cand) {
+                        closest_take(t, (int)pend_k, sphere, T, idx, cur_sphere);
+                        limit = __builtin_fminf(T + slack, t_stop);
+                    }
+                }
+            }
+        }
+        // ---- a finished walk with nothing parked: the ray is done ----
+        if (alive && over && !pend) {
+            if (ANY) U(w, F_RES_ANY, pix) = 1u;  // nothing in the way
+            else store_closest_result(w, pix, T, idx);
+            alive = false;
+        }
+    }
+    if (STATS) {
+        unsigned long long* acc = w.rp.counters->walk[ANY ? 1 : 0];
+        const unsigned long long v[8] = {wave_sum64(s_rays), s_trips, s_live, wave_sum64(s_fetch), wave_sum64(s_pre), wave_sum64(tested), s_flush, s_refill};
+        if (lane == 0u)
+            for (int j = 0; j < 8; ++j)
+                if (v[j]) atomicAdd(&acc[j], v[j]);
+    }
+}
+
+template <bool FUSED, bool ANY, bool STATS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK2_WAVES))) void wf_walk(const WfParams wk, uint32_t* __restrict__ run_ctr) {
+    WfParams w = wk;
+    if (!resolve_round(w)) return;
+    const uint32_t* queue = ANY ? w.q_prev_any : w.q_prev_closest;
+    const uint32_t n_queue = ANY ? w.n_prev_any : w.n_prev_closest;
+    if (n_queue == 0u) return;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * 256u) >> 6;
+    unsigned long long tested = 0;
+    walk_segment<FUSED, ANY, STATS>(w, queue, n_queue, wave, n_waves, run_ctr, tested);
+    if (STATS && tested) atomicAdd(&w.rp.counters->tests, tested);
+}
+
 // Literal shadow test: the reference's full closest hit, then its `time >= 1 || time < 0` (:229).
 template <bool FUSED>
 __global__ __launch_bounds__(256) void wf_trace_any_literal(const WfParams wk) {
@@ -1395,6 +1671,15 @@ static void launch_persistent(const WfParams& w, uint64_t n_max, uint32_t* ticke
     const uint64_t any_cap = std::min<uint64_t>(RT_MAX_WAVES_ANY_SHARED, n_max <= (3ull << 20) ? 2048u : 4096u);
     const dim3 grid = persistent_grid(n_max, ANY ? any_cap : (shared ? RT_MAX_WAVES_CLOSEST_SHARED : RT_MAX_WAVES)), block(256);
     const bool tri = w.grid.has_triangles != 0u;
+    // scenes without triangles: the unified walk (walk_segment), where its record table was built; RT_WALK2=closest / any /
+    // none picks which of the two walks use it (measurement knob)
+    static const char* walk2_env = std::getenv("RT_WALK2");
+    const bool walk2_allowed = !walk2_env || (ANY ? std::strcmp(walk2_env, "any") == 0 : std::strcmp(walk2_env, "closest") == 0) || std::strcmp(walk2_env, "both") == 0;
+    if (!tri && w.grid.walk_rec && walk2_allowed && (!ANY || !w.ltiles.enabled || w.ltiles.walk_base != 0u)) {
+        if (w.count_rays) hipLaunchKernelGGL((wf_walk<FUSED, ANY, true>), grid, block, 0, s, w, ticket);
+        else hipLaunchKernelGGL((wf_walk<FUSED, ANY, false>), grid, block, 0, s, w, ticket);
+        return;
+    }
     if (w.count_rays) {
         if (tri) hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, true, true>), grid, block, 0, s, w, ticket);
         else hipLaunchKernelGGL((wf_trace_grid_persistent<FUSED, ANY, true, false>), grid, block, 0, s, w, ticket);
