@@ -75,6 +75,9 @@ struct rt_context {
     uint2* d_lt_range = nullptr;            // light tiles (rt_grid.h: LightTiles) for the last light's shadow rays
     float4* d_lt_records = nullptr;
     rt::LightTiles light_tiles = {};
+    rt::BlockGrid blocks = {};              // the closest-hit walk's coarse grid of 32-byte blocks (rt_grid.h: BlockGrid)
+    uint4* d_walk_blocks = nullptr;
+    uint32_t* d_walk_ids = nullptr;
     std::vector<float4> h_walk;             // the unified walk's records while they are being put together (rt_grid.h: GridDesc::walk_rec)
     float4* d_walk_rec = nullptr;
     uint32_t* d_tile_start = nullptr;       // screen tiles (64 x 8 pixels) -> objects a pinhole primary ray can reach
@@ -454,6 +457,7 @@ int ensure_wavefront(rt_context* c) {
     b.shadow_pairs = c->d_shadow_pairs;
     b.grid = c->grid;
     b.light_tiles = c->light_tiles;
+    b.blocks = c->blocks;
     b.capacity = n;
     return RT_OK;
 }
@@ -712,6 +716,177 @@ int upload_walk_records(rt_context* c) {
     RT_HIP(c, hipMemcpy(c->d_walk_rec, c->h_walk.data(), sizeof(float4) * c->h_walk.size(), hipMemcpyHostToDevice));
     c->grid.walk_rec = c->d_walk_rec;
     std::vector<float4>().swap(c->h_walk);
+    return RT_OK;
+}
+
+// The closest-hit walk's coarse grid of 32-byte blocks (rt_grid.h: BlockGrid). Same box and same objects as the fine grid;
+// an object sits in every block-cell its registration sphere reaches (the fine grid's radius with the walk-arithmetic slack
+// re-sized to this grid's cell). Every entry's sphere is rounded OUTWARDS onto its block's lattice - see the struct's comment;
+// the derivation of the radius: with the centre off by delta (quantisation error, known exactly, + the rounding of the
+// ray's transform into lattice coordinates), "the line passes c within sqrt(w^2 + a |oc|^2)" (a = 6e-6 K^2, the pre-test's
+// distance term) implies "it passes c' within sqrt(w'^2 + a |oc'|^2)" for
+//     w'^2 = (w + delta)^2 + 2 delta sqrt(a) D + a (2 delta D + delta^2),     D = the largest possible |oc|,
+// and a sphere that contains the original can only be "entirely behind the origin" if the original is.
+int build_walk_blocks(rt_context* c, uint32_t n, const std::vector<Bound>& sph, const std::vector<double>& rg, double cell_fine,
+                      const double glo[3], const double ghi[3], double K2) {
+    c->blocks = rt::BlockGrid{};
+    if (std::getenv("RT_NO_WALK3") || c->h_grid_pre.size() != n) return RT_OK;  // (measurement knob: the record walk)
+    double factor = 1.67;
+    if (const char* env = std::getenv("RT_WALK_BLOCK_FACTOR")) {  // tuning knob (results do not depend on it)
+        const double v = std::atof(env);
+        if (v >= 0.25 && v <= 16.0) factor = v;
+    }
+    const double cell = cell_fine * factor;
+    const float cellf = (float)cell;
+    const float lof[3] = {(float)glo[0], (float)glo[1], (float)glo[2]};
+    const int B = (int)rt::kBlockBorder;
+    int dim[3];
+    uint64_t wn[3];
+    for (int a = 0; a < 3; ++a) {
+        dim[a] = (int)std::ceil((ghi[a] - (double)lof[a]) / (double)cellf) + 1;
+        if (dim[a] < 1) dim[a] = 1;
+        if (dim[a] > 1040) return RT_OK;
+        wn[a] = (uint64_t)dim[a] + 2 * B;
+    }
+    const uint64_t n_cells = wn[0] * wn[1] * wn[2];
+    if (n_cells >= (1ull << 24)) return RT_OK;  // block indices are 24 bits in a header
+    float c0[3];
+    for (int a = 0; a < 3; ++a) c0[a] = (float)((double)lof[a] + (0.5 - B) * (double)cellf);
+    const volatile float inv_step_v = 128.0f / cellf;
+    const float inv_step = inv_step_v;
+    double Dmax = 0;
+    for (int a = 0; a < 3; ++a) Dmax += (ghi[a] - glo[a] + 2 * cell) * (ghi[a] - glo[a] + 2 * cell);
+    Dmax = std::sqrt(Dmax);
+    const double alpha0 = 6e-6 * K2, sq_alpha0 = std::sqrt(alpha0);
+    // registration (as build_grid: the cells the registration SPHERE reaches)
+    std::vector<uint32_t> start(n_cells + 1, 0), entries, fill;
+    auto cell_index = [&](int x, int y, int z) { return (size_t)((((uint64_t)(z + B)) * wn[1] + (uint64_t)(y + B)) * wn[0] + (uint64_t)(x + B)); };
+    uint64_t total = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) {
+            for (size_t k = 0; k < (size_t)n_cells; ++k) start[k + 1] += start[k];
+            total = start[n_cells];
+            if (total > 0x7fffffffull) return RT_OK;
+            entries.assign((size_t)total, 0);
+            fill.assign(start.begin(), start.end() - 1);
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            if (!(rg[i] >= 0) || !std::isfinite(rg[i])) continue;
+            const double rb = rg[i] - 0.01 * cell_fine + 0.01 * cell;
+            const double cc[3] = {sph[i].x, sph[i].y, sph[i].z};
+            int lo_i[3], hi_i[3];
+            for (int a = 0; a < 3; ++a) {
+                lo_i[a] = std::max((int)std::floor((cc[a] - rb - (double)lof[a]) / (double)cellf), 0);
+                hi_i[a] = std::min((int)std::floor((cc[a] + rb - (double)lof[a]) / (double)cellf), dim[a] - 1);
+            }
+            const double r2 = rb * rb;
+            auto gap2 = [&](int a, int k) {
+                const double w0 = (double)lof[a] + (double)cellf * k, w1 = w0 + (double)cellf;
+                const double d = cc[a] < w0 ? w0 - cc[a] : (cc[a] > w1 ? cc[a] - w1 : 0.0);
+                return d * d;
+            };
+            for (int z = lo_i[2]; z <= hi_i[2]; ++z) {
+                const double dz2 = gap2(2, z);
+                for (int y = lo_i[1]; y <= hi_i[1]; ++y) {
+                    const double dyz2 = dz2 + gap2(1, y);
+                    if (dyz2 > r2) continue;
+                    for (int x = lo_i[0]; x <= hi_i[0]; ++x) {
+                        if (dyz2 + gap2(0, x) > r2) continue;
+                        const size_t k = cell_index(x, y, z);
+                        if (pass == 0) { start[k + 1] += 1; if (++total > 64ull * n + 1024ull) return RT_OK; }
+                        else entries[fill[k]++] = i;
+                    }
+                }
+            }
+        }
+    }
+    // blocks
+    struct Enc { uint32_t word; uint32_t id; int s; };
+    std::vector<uint32_t> blocks((size_t)n_cells * 8, 0u), ids((size_t)n_cells * 8, c->n_objs);
+    uint64_t hist[5] = {0, 0, 0, 0, 0}, chain_blocks = 0;
+    std::vector<Enc> enc;
+    for (uint64_t wz = 0; wz < wn[2]; ++wz)
+        for (uint64_t wy = 0; wy < wn[1]; ++wy)
+            for (uint64_t wx = 0; wx < wn[0]; ++wx) {
+                const size_t k = (size_t)((wz * wn[1] + wy) * wn[0] + wx);
+                const uint32_t cnt = start[k + 1] - start[k];
+                if (cnt == 0) continue;
+                const float Cdev[3] = {std::fmaf((float)wx, cellf, c0[0]), std::fmaf((float)wy, cellf, c0[1]), std::fmaf((float)wz, cellf, c0[2])};
+                enc.clear();
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const uint32_t i = entries[start[k] + j];
+                    const double w = std::fabs((double)c->h_grid_pre[i]);
+                    const double cc[3] = {sph[i].x, sph[i].y, sph[i].z};
+                    Enc e{(255u << 24) | (128u << 16) | (128u << 8) | 128u, i, 3};  // the whole cell and then some: 255 steps of cell / 16 around its centre
+                    bool found = false;
+                    for (int sc = 0; sc < 4 && !found; ++sc) {
+                        const double inv = (double)inv_step * std::ldexp(1.0, -sc), step = 1.0 / inv;
+                        double d2 = 0;
+                        int q[3];
+                        bool ok = true;
+                        for (int a = 0; a < 3; ++a) {
+                            const double u = (cc[a] - (double)Cdev[a]) * inv + 128.0;
+                            q[a] = (int)std::floor(u + 0.5);
+                            if (q[a] < 0 || q[a] > 255) ok = false;
+                            d2 += (u - q[a]) * (u - q[a]);
+                        }
+                        if (!ok) continue;
+                        // centre error in view-space units + the rounding of the device's transform of the ray origin
+                        const double delta = std::sqrt(d2) * step + 1.5 * 5.97e-8 * (2.0 * Dmax + 128.0 * step);
+                        const double w2 = (w + delta) * (w + delta) + 2.0 * delta * sq_alpha0 * Dmax + alpha0 * (2.0 * delta * Dmax + delta * delta);
+                        const double r_lat = std::sqrt(w2) * (1.0 + 1e-6) * inv + 1e-3;
+                        const int r = (int)std::ceil(r_lat);
+                        if (r > 255) continue;
+                        e = Enc{((uint32_t)r << 24) | ((uint32_t)q[2] << 16) | ((uint32_t)q[1] << 8) | (uint32_t)q[0], i, sc};
+                        found = true;
+                    }
+                    hist[found ? e.s : 4] += 1;
+                    enc.push_back(e);
+                }
+                std::stable_sort(enc.begin(), enc.end(), [](const Enc& a, const Enc& b) { return a.s < b.s; });
+                size_t at = k, pos = 0;
+                while (pos < enc.size()) {
+                    const int sc = enc[pos].s;
+                    uint32_t m = 0;
+                    while (m < rt::kBlockEntries && pos < enc.size() && enc[pos].s == sc) {
+                        blocks[at * 8 + 1 + m] = enc[pos].word;
+                        ids[at * 8 + m] = enc[pos].id;
+                        ++m; ++pos;
+                    }
+                    uint32_t next = 0;
+                    if (pos < enc.size()) {
+                        next = (uint32_t)(blocks.size() / 8);
+                        if (next >= (1u << 24)) return RT_OK;
+                        blocks.resize(blocks.size() + 8, 0u);
+                        ids.resize(ids.size() + 8, c->n_objs);
+                        ++chain_blocks;
+                    }
+                    blocks[at * 8] = next | ((uint32_t)sc << 27);
+                    at = next;
+                }
+            }
+    if ((uint64_t)blocks.size() * 4ull >= 0xf0000000ull) return RT_OK;
+    RT_HIP(c, hipMalloc((void**)&c->d_walk_blocks, sizeof(uint32_t) * blocks.size()));
+    RT_HIP(c, hipMalloc((void**)&c->d_walk_ids, sizeof(uint32_t) * ids.size()));
+    RT_HIP(c, hipMemcpy(c->d_walk_blocks, blocks.data(), sizeof(uint32_t) * blocks.size(), hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(c->d_walk_ids, ids.data(), sizeof(uint32_t) * ids.size(), hipMemcpyHostToDevice));
+    rt::BlockGrid& b = c->blocks;
+    b.lox = lof[0]; b.loy = lof[1]; b.loz = lof[2];
+    b.cell = cellf;
+    b.inv_cell = 1.0f / cellf;
+    b.nx = dim[0]; b.ny = dim[1]; b.nz = dim[2];
+    b.c0x = c0[0]; b.c0y = c0[1]; b.c0z = c0[2];
+    b.inv_step = inv_step;
+    b.wnx = (uint32_t)wn[0]; b.wny = (uint32_t)wn[1];
+    b.n_cells = (uint32_t)n_cells;
+    b.blocks = c->d_walk_blocks;
+    b.ids = c->d_walk_ids;
+    b.none = c->n_objs;
+    b.enabled = 1u;
+    if (std::getenv("RT_WALK_STATS"))
+        std::fprintf(stderr, "[blocks] %d x %d x %d cells, edge %g, %llu entries, %zu blocks (%llu chained), scale 0/1/2/3/whole-cell: %llu %llu %llu %llu %llu\n",
+                     dim[0], dim[1], dim[2], (double)cellf, (unsigned long long)total, blocks.size() / 8, (unsigned long long)chain_blocks,
+                     (unsigned long long)hist[0], (unsigned long long)hist[1], (unsigned long long)hist[2], (unsigned long long)hist[3], (unsigned long long)hist[4]);
     return RT_OK;
 }
 
@@ -999,6 +1174,10 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     }
     g.pretest_alpha = std::nextafter((float)(6e-6 * K2 + 8e-6), std::numeric_limits<float>::infinity());
     g.enabled = 1u;
+    if (!c->has_triangles) {
+        const int rc = build_walk_blocks(c, n, sph, rg, cell, glo, ghi, K2);
+        if (rc != RT_OK) return rc;
+    }
     c->h_grid_spheres.resize(4 * (size_t)n);
     for (uint32_t i = 0; i < n; ++i) {
         c->h_grid_spheres[4 * i] = sph[i].x; c->h_grid_spheres[4 * i + 1] = sph[i].y; c->h_grid_spheres[4 * i + 2] = sph[i].z;
@@ -1519,6 +1698,8 @@ void rt_destroy(rt_context* c) {
     if (c->d_lt_range) (void)hipFree(c->d_lt_range);
     if (c->d_lt_records) (void)hipFree(c->d_lt_records);
     if (c->d_walk_rec) (void)hipFree(c->d_walk_rec);
+    if (c->d_walk_blocks) (void)hipFree(c->d_walk_blocks);
+    if (c->d_walk_ids) (void)hipFree(c->d_walk_ids);
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->d_out) (void)hipFree(c->d_out);

@@ -77,6 +77,40 @@ struct GridDesc {
     uint32_t walk_none;
 };
 
+// The block walk (rt_wavefront.hip: block_segment; closest-hit rays of scenes without triangles). What bounds a grid walk
+// on this chip is neither instruction issue nor latency but the number of cache LINES its lanes pull per second: a
+// dependent random fetch costs a CU ~5 cycles per line that misses L2 and ~3 per line that hits, whether 16 or 64 of
+// its bytes are used and whether 4 or 8 waves per SIMD are resident (tools/ubench/gather_rate.hip). So a fetch should
+// carry as many candidates as a line can hold. A SECOND, coarser grid over the same box, one 32-byte block per cell:
+//   word 0      header: next block of the cell's chain (bits 0-23, 0 = none), lattice scale s (bits 27-28)
+//   words 1-7   one candidate each, its bounding sphere quantised to 8 bits per field {x, y, z, r} on a lattice of 256
+//               steps centred on the cell: step = 2^s cell / 128, i.e. scale 0 reaches half a cell beyond the cell on
+//               every side (unused slots: all zero - a sphere of radius 0 at a lattice corner; should a ray ever pass
+//               its pre-test, its id is the never-hit dummy object)
+// and a parallel array of object ids (8 per block), read only for the few entries that pass the pre-test. The pre-test
+// is the one of misses_bounding_sphere, evaluated in lattice coordinates (a similarity transform: the ray origin is
+// moved there once per trip). The host (rt_api.cpp: build_walk_blocks) rounds every sphere OUTWARDS: it computes the
+// lattice the way the device does (same fp32 fma), knows each entry's exact quantisation error and adds it - plus the
+// transform's rounding and the cross term of the distance-dependent tolerance - to the radius; a sphere that does not
+// fit any scale becomes "the whole cell". Seven candidates per line instead of one: cells can be ~1.7x larger, a ray
+// pulls ~14 lines instead of ~34 and the table fits an XCD's L2. The array carries two empty cells on every side (as
+// GridDesc::walk_rec: walks end by parameter, inside the border).
+struct BlockGrid {
+    float lox, loy, loz;       // origin of the grid proper (view space)
+    float cell, inv_cell;
+    int nx, ny, nz;            // cells of the grid proper
+    float c0x, c0y, c0z;       // centre of padded cell (0, 0, 0); padded cell f has its centre at fma(f, cell, c0)
+    float inv_step;            // lattice steps per unit at scale 0 (128 / cell)
+    uint32_t wnx, wny;         // padded array: cells per row, rows per slab
+    uint32_t n_cells;          // head blocks (one per padded cell); chain blocks follow
+    const uint4* __restrict__ blocks;   // 2 x uint4 per block
+    const uint32_t* __restrict__ ids;   // 8 per block (slot e of block b: ids[8 b + e]; slot 7 unused)
+    uint32_t none;             // the never-hit dummy object
+    uint32_t enabled;
+};
+constexpr uint32_t kBlockBorder = 2;
+constexpr uint32_t kBlockEntries = 7;
+
 // Element `index` of a read-only table smaller than 4 GiB (build_grid / build_light_tiles refuse larger ones): the byte
 // offset is formed in 32 bits, so the load takes the scalar-base + 32-bit-vector-offset form instead of a 64-bit vector
 // address computed with two more vector instructions per load - the walk does three such loads per trip.
@@ -252,7 +286,8 @@ struct Walk {
 // The walk's own arithmetic uses the hardware reciprocal (1 ulp) instead of IEEE division: t values are only used
 // to order cell crossings, and their error (~1e-7 relative, i.e. < 1e-4 of a cell over the whole scene) sits far
 // inside the 0.01-cell slack every registered radius carries for exactly this purpose.
-__device__ __forceinline__ Walk walk_begin(const GridDesc& g, const Ray& ray, float t_limit) {
+template <typename GRID>
+__device__ __forceinline__ Walk walk_begin(const GRID& g, const Ray& ray, float t_limit) {
     Walk w;
     w.alive = false;
     // the ray as a 3-D segment (the reference divides nothing by w here; start.w scales nothing in view space:

@@ -43,6 +43,7 @@ struct WavefrontBuffers {
     GridDesc grid = {};                            // conservative grid (owned by the context); enabled = 0 -> brute force
     ScreenTiles tiles = {};                        // per-screen-tile object lists for pinhole primary rays
     LightTiles light_tiles = {};                   // per-direction object lists for the shadow rays of the last light
+    BlockGrid blocks = {};                         // the closest-hit walk's coarse grid of 32-byte blocks (owned by the context)
     uint32_t* counts = nullptr;                    // device-side round state (queue lengths, hand-over flags) + run-ticket counters
     uint32_t* h_counts = nullptr;                  // 16 x uint32 pinned host mirror of the round state
     uint64_t capacity = 0;                         // n_local the buffers were sized for

@@ -83,6 +83,7 @@ struct WfParams {
     GridDesc grid;                // conservative uniform grid (enabled = 0: brute force)
     ScreenTiles tiles;            // screen-tile object lists for pinhole primary rays
     LightTiles ltiles;            // light tiles for the last light's shadow rays
+    BlockGrid bgrid;              // the closest-hit walk's coarse grid of 32-byte blocks (enabled = 0: walk_segment / trace_segment)
     uint32_t n_prev_closest, n_prev_any;
     int kernel;
     uint32_t first_round;  // the closest-hit rays of this round are the primary rays (never stored: closest_ray())
@@ -986,6 +987,254 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK2_WA
     if (STATS && tested) atomicAdd(&w.rp.counters->tests, tested);
 }
 
+// ---- grid traversal, block form (closest-hit rays, scenes without triangles) ----------------------------------------------
+// rt_grid.h: BlockGrid says why: the walk is bound by the cache lines its lanes pull, so a trip fetches ONE 32-byte block
+// with up to seven candidates (8-bit lattice spheres) and pre-tests them all; object ids are fetched only for the few that
+// pass. Everything else is walk_segment: one parking slot, exact tests run for the whole wave, order-free update, walks that
+// end by parameter inside the table's empty border.
+#ifndef RT_WALK3_WAVES
+#define RT_WALK3_WAVES 6
+#endif
+
+// candidate `word` = {x, y, z, r} (8 bits each) of a block's lattice against a ray whose origin is (olx, oly, olz) in lattice
+// coordinates: the pre-test of misses_bounding_sphere (a similarity transform leaves every sign it looks at unchanged),
+// written without boolean plumbing - the walk runs seven of these per trip and was paying ~8 scalar instructions of mask
+// logic for each. With oo = |o - c|^2, od = (c - o) . d:
+//     line misses:      od^2 - dd (oo (1 - alpha) - r^2) < 0
+//     entirely behind:  od < 0  and  oo (1 - 1e-5) - r^2 > 0
+//     miss  <=>  max(-disc, min(-od, behind)) > 0          (no NaN can arise for the rays this walk accepts)
+// Returns pm with the verdict shifted in from the right (1 = passes): the caller feeds the entries last to first.
+__device__ __forceinline__ uint32_t lattice_pretest(uint32_t pm, uint32_t word, float olx, float oly, float olz, float dx, float dy, float dz,
+                                                    float neg_dd, float one_minus_alpha) {
+    const float x = (float)(word & 0xffu), y = (float)((word >> 8) & 0xffu), z = (float)((word >> 16) & 0xffu), r = (float)(word >> 24);
+    const float ox = x - olx, oy = y - oly, oz = z - olz;
+    const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float od = __builtin_fmaf(oz, dz, __builtin_fmaf(oy, dy, ox * dx));
+    const float r2 = r * r;
+    const float disc = __builtin_fmaf(neg_dd, __builtin_fmaf(one_minus_alpha, oo, -r2), od * od);
+    const float behind = __builtin_fmaf(0.99999f, oo, -r2);
+    const float s = __builtin_fmaxf(-disc, __builtin_fminf(-od, behind));
+    return pm + pm + (s > 0.f ? 0u : 1u);
+}
+
+template <bool FUSED, bool STATS>
+__device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue,
+                                              uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr,
+                                              unsigned long long& tested) {
+    const uint32_t lane = threadIdx.x & 63u;
+    // runs and tickets: as trace_segment
+    uint32_t seg = kSegment;
+    while (seg > 64u && n_queue < 2u * n_waves * seg) seg >>= 1;
+    const uint32_t n_runs = (n_queue + seg - 1u) / seg;
+    const bool dynamic = n_runs > n_waves;
+    uint32_t next = 0, seg_end = 0;
+    uint32_t region = 0, regions_tried = 0;
+    if (kTicketRegions > 1u) {
+        uint32_t xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        region = (xcc & 0xfu) % kTicketRegions;
+    }
+    auto grab = [&]() -> bool {
+        for (;;) {
+            const uint32_t lo = (uint32_t)(((uint64_t)n_runs * region) / kTicketRegions);
+            const uint32_t hi = (uint32_t)(((uint64_t)n_runs * (region + 1u)) / kTicketRegions);
+            uint32_t r = 0;
+            if (lane == 0u) r = atomicAdd(run_ctr + region * kTicketStride, 1u);
+            r = __builtin_amdgcn_readfirstlane(r) + lo;
+            if (r < hi) {
+                next = r * seg;
+                seg_end = (n_queue - next < seg) ? n_queue : next + seg;
+                return true;
+            }
+            if (++regions_tried >= kTicketRegions) return false;
+            region = (region + 1u == kTicketRegions) ? 0u : region + 1u;
+        }
+    };
+    bool more = dynamic;
+    if (dynamic) {
+        if (!grab()) return;
+    } else {
+        if (wave >= n_runs) return;
+        next = wave * seg;
+        seg_end = (n_queue - next < seg) ? n_queue : next + seg;
+    }
+    const GridDesc& g = w.grid;
+    const BlockGrid& bg = w.bgrid;
+    const HotObject* __restrict__ hot = w.rp.scene.hot;
+    const float wnx_f = (float)bg.wnx, wny_f = (float)bg.wny;
+
+    unsigned long long s_rays = 0, s_trips = 0, s_live = 0, s_fetch = 0, s_pre = 0, s_flush = 0, s_refill = 0;  // STATS only
+    bool alive = false;   // the lane holds a ray ...
+    bool over = false;    // ... whose walk has ended (it may still wait for its parked exact test)
+    uint32_t pix = 0;
+    float rsx = 0.f, rsy = 0.f, rsz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, dd = 0.f;
+    uint32_t cur = 0;                         // block to look at next (bits 0-23) and the entry to resume it at (bits 24-26)
+    float fx = 0.f, fy = 0.f, fz = 0.f;       // current cell, padded coordinates (whole numbers)
+    float tx = 0.f, ty = 0.f, tz = 0.f, dtx = 0.f, dty = 0.f, dtz = 0.f;
+    float T = kMaxFloat, limit = 0.f, t_stop = 0.f, slack = 0.f;
+    int idx = -1;
+    bool cur_sphere = false;
+    bool pend = false;
+    uint32_t pend_k = 0, done_k = 0xffffffffu;
+
+    for (;;) {
+        // ---- hand out rays to idle lanes ----
+        const unsigned long long idle = __ballot(!alive);
+        if (next < seg_end && ((uint32_t)__popcll(idle) >= (uint32_t)RT_WALK2_REFILL_MIN || idle == ~0ull)) {
+            const uint32_t mine = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+            if (STATS && lane == 0u) ++s_refill;
+            if (!alive && mine < seg_end) {
+                if (STATS) ++s_rays;
+                const uint32_t entry = w.identity_queue ? mine : queue[mine];
+                pix = w.identity_queue ? mine : (entry & kQueuePixel);
+                Ray ray = closest_ray(w, pix, w.first_round != 0u);
+                const uint32_t note = __float_as_uint(ray.dw);  // begin_shade_lit's note: the object a reflection ray leaves
+                ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
+                rsx = ray.sx; rsy = ray.sy; rsz = ray.sz; rdx = ray.dx; rdy = ray.dy; rdz = ray.dz;
+                T = kMaxFloat; idx = -1; cur_sphere = false; pend = false; over = false;
+                done_k = (w.first_round == 0u) ? note : 0xffffffffu;
+                dd = rdx * rdx + rdy * rdy + rdz * rdz;
+                slack = dd > 0.f ? kWalkSlackCells * bg.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
+                bool start = false, brute = false;
+                const Walk w0 = walk_begin(bg, ray, 3.0e38f);  // (a ray with a NaN in it: not alive)
+                if (w0.alive) {
+                    // (walk_segment: the rays this walk is made for; anything else tests every object here and now)
+                    const float dmin = __builtin_fminf(__builtin_fminf(w0.dtx, w0.dty), w0.dtz);
+                    const bool tame = dd > 1.0e-30f && dd < 1.0e30f && w0.t_enter <= 4096.f * dmin;
+                    brute = !tame;
+                    start = tame;
+                    fx = (float)(w0.ix + (int)kBlockBorder); fy = (float)(w0.iy + (int)kBlockBorder); fz = (float)(w0.iz + (int)kBlockBorder);
+                    cur = ((uint32_t)(w0.iz + (int)kBlockBorder) * bg.wny + (uint32_t)(w0.iy + (int)kBlockBorder)) * bg.wnx + (uint32_t)(w0.ix + (int)kBlockBorder);
+                    tx = w0.tx; ty = w0.ty; tz = w0.tz; dtx = w0.dtx; dty = w0.dty; dtz = w0.dtz;
+                    t_stop = __builtin_fminf(w0.t_exit + 0.25f * dmin, 3.0e38f);
+                }
+                {   // objects every ray must test (usually none); a ray the walk is not made for tests them all
+                    const uint32_t n_loop = brute ? w.rp.scene.n_objs : g.n_always;
+                    for (uint32_t a = 0; a < n_loop; ++a) {
+                        const int k = brute ? (int)a : (int)g.always[a];
+                        float t;
+                        bool sphere;
+                        const bool cand = lane_candidate<FUSED, true, false>(hot + k, ray, t, sphere);
+                        if (STATS) ++tested;
+                        if (cand) closest_take(t, k, sphere, T, idx, cur_sphere);
+                    }
+                    limit = __builtin_fminf(T + slack, t_stop);
+                }
+                if (!start) store_closest_result(w, pix, T, idx);  // no cell to look at, or everything tested already
+                else alive = true;
+            }
+            next += (uint32_t)__popcll(idle);
+            if (next >= seg_end && more) more = grab();  // on to another run, if any is left
+        }
+        const unsigned long long live = __ballot(alive);
+        if (live == 0ull) {
+            if (next >= seg_end) break;
+            continue;
+        }
+        // ---- one trip: the block under the cursor ----
+        const bool walking = alive && !over;
+        bool stall = false;
+        if (STATS) { if (lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); } if (walking) { s_pre += kBlockEntries; if ((cur & 0xffffffu) < bg.n_cells) ++s_fetch; } }
+        if (walking) {
+            const uint32_t b = cur & 0xffffffu, pos = cur >> 24;
+            const uint4 q0 = table_at(bg.blocks, 2u * b);
+            const uint4 q1 = table_at(bg.blocks, 2u * b + 1u);
+            const uint32_t nxt = q0.x & 0xffffffu;
+            const float inv = __builtin_ldexpf(bg.inv_step, -(int)((q0.x >> 27) & 3u));
+            // the ray's origin in the lattice of this block: 256 steps centred on the current cell
+            const float olx = __builtin_fmaf(rsx - __builtin_fmaf(fx, bg.cell, bg.c0x), inv, 128.0f);
+            const float oly = __builtin_fmaf(rsy - __builtin_fmaf(fy, bg.cell, bg.c0y), inv, 128.0f);
+            const float olz = __builtin_fmaf(rsz - __builtin_fmaf(fz, bg.cell, bg.c0z), inv, 128.0f);
+            uint32_t pm = 0u;  // candidates that pass the pre-test: bit e = entry e (fed last to first)
+            const float neg_dd = -dd, oma = 1.0f - g.pretest_alpha;
+            pm = lattice_pretest(pm, q1.w, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            pm = lattice_pretest(pm, q1.z, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            pm = lattice_pretest(pm, q1.y, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            pm = lattice_pretest(pm, q1.x, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            pm = lattice_pretest(pm, q0.w, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            pm = lattice_pretest(pm, q0.z, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            pm = lattice_pretest(pm, q0.y, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            pm &= 0x7fu << pos;  // (a block the lane comes back to: the entries before `pos` have been dealt with)
+            uint32_t back = 0u;
+            while (pm != 0u) {  // few lanes, seldom more than once: the ids of the candidates that passed
+                const uint32_t e = (uint32_t)__builtin_ctz(pm);
+                const uint32_t k = table_at(bg.ids, 8u * b + e);
+                // the same object again (parked, or tested a cell ago)? its result is known or on its way
+                const bool dup = (k == done_k) || (pend && k == pend_k);
+                if (!dup) {
+                    if (pend) { stall = true; back = e; break; }  // one parking slot: wait for the exact tests, resume here
+                    pend = true;
+                    pend_k = k;
+                }
+                pm &= pm - 1u;
+            }
+            const bool adv = !stall && nxt == 0u;  // the chain ends here: on to the next cell
+            // the DDA step, computed by every lane, taken by those that advance (ties: x before y before z, as walk_next)
+            const float tmin = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+            const bool ax = (tx <= ty) && (tx <= tz);
+            const bool ay = !ax && (ty <= tz);
+            const bool az = !ax && !ay;
+            tx += (adv && ax) ? dtx : 0.f;
+            ty += (adv && ay) ? dty : 0.f;
+            tz += (adv && az) ? dtz : 0.f;
+            fx += (adv && ax) ? __builtin_copysignf(1.0f, rdx) : 0.f;
+            fy += (adv && ay) ? __builtin_copysignf(1.0f, rdy) : 0.f;
+            fz += (adv && az) ? __builtin_copysignf(1.0f, rdz) : 0.f;
+            over = adv && tmin > limit;
+            const uint32_t cell = (uint32_t)__builtin_fmaf(__builtin_fmaf(fz, wny_f, fy), wnx_f, fx);  // (whole numbers below 2^24: exact)
+            cur = stall ? (b | (back << 24)) : (adv ? cell : nxt);
+        }
+        // ---- the exact tests, when enough lanes wait for them ----
+        const unsigned long long pending = __ballot(pend);
+        if (pending != 0ull) {
+            const unsigned long long stuck = __ballot(pend && (stall || over));
+            const uint32_t n_live = (uint32_t)__popcll(live);
+            if ((uint32_t)__popcll(pending) >= (uint32_t)RT_WALK2_DEFER_PENDING ||
+                ((uint32_t)__popcll(stuck) << RT_DEFER_STUCK_SHIFT) >= n_live) {
+                if (STATS && lane == 0u) ++s_flush;
+                if (pend) {
+                    float t;
+                    bool sphere;
+                    const Ray ray = {rsx, rsy, rsz, 1.0f, rdx, rdy, rdz, 0.0f};
+                    const bool cand = lane_candidate<FUSED, true, false>(hot + pend_k, ray, t, sphere);
+                    if (STATS) ++tested;
+                    pend = false;
+                    done_k = pend_k;
+                    if (cand) {
+                        closest_take(t, (int)pend_k, sphere, T, idx, cur_sphere);
+                        limit = __builtin_fminf(T + slack, t_stop);
+                    }
+                }
+            }
+        }
+        // ---- a finished walk with nothing parked: the ray is done ----
+        if (alive && over && !pend) {
+            store_closest_result(w, pix, T, idx);
+            alive = false;
+        }
+    }
+    if (STATS) {
+        unsigned long long* acc = w.rp.counters->walk[0];
+        const unsigned long long v[8] = {wave_sum64(s_rays), s_trips, s_live, wave_sum64(s_fetch), wave_sum64(s_pre), wave_sum64(tested), s_flush, s_refill};
+        if (lane == 0u)
+            for (int j = 0; j < 8; ++j)
+                if (v[j]) atomicAdd(&acc[j], v[j]);
+    }
+}
+
+template <bool FUSED, bool STATS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK3_WAVES))) void wf_walk_blocks(const WfParams wk, uint32_t* __restrict__ run_ctr) {
+    WfParams w = wk;
+    if (!resolve_round(w)) return;
+    const uint32_t n_queue = w.n_prev_closest;
+    if (n_queue == 0u) return;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * 256u) >> 6;
+    unsigned long long tested = 0;
+    block_segment<FUSED, STATS>(w, w.q_prev_closest, n_queue, wave, n_waves, run_ctr, tested);
+    if (STATS && tested) atomicAdd(&w.rp.counters->tests, tested);
+}
+
 // Literal shadow test: the reference's full closest hit, then its `time >= 1 || time < 0` (:229).
 template <bool FUSED>
 __global__ __launch_bounds__(256) void wf_trace_any_literal(const WfParams wk) {
@@ -1674,6 +1923,12 @@ static void launch_persistent(const WfParams& w, uint64_t n_max, uint32_t* ticke
     // scenes without triangles: the unified walk (walk_segment), where its record table was built; RT_WALK2=closest / any /
     // none picks which of the two walks use it (measurement knob)
     static const char* walk2_env = std::getenv("RT_WALK2");
+    static const char* walk3_env = std::getenv("RT_WALK3");  // "0": closest-hit rays through walk_segment / trace_segment instead
+    if (!ANY && !tri && w.bgrid.enabled && !(walk3_env && walk3_env[0] == '0')) {
+        if (w.count_rays) hipLaunchKernelGGL((wf_walk_blocks<FUSED, true>), grid, block, 0, s, w, ticket);
+        else hipLaunchKernelGGL((wf_walk_blocks<FUSED, false>), grid, block, 0, s, w, ticket);
+        return;
+    }
     const bool walk2_allowed = !walk2_env || (ANY ? std::strcmp(walk2_env, "any") == 0 : std::strcmp(walk2_env, "closest") == 0) || std::strcmp(walk2_env, "both") == 0;
     if (!tri && w.grid.walk_rec && walk2_allowed && (!ANY || !w.ltiles.enabled || w.ltiles.walk_base != 0u)) {
         if (w.count_rays) hipLaunchKernelGGL((wf_walk<FUSED, ANY, true>), grid, block, 0, s, w, ticket);
@@ -1703,6 +1958,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
     w.grid = buf.grid;
     w.tiles = buf.tiles;
     w.ltiles = buf.light_tiles;
+    w.bgrid = buf.blocks;
     for (int a = 0; a < 2; ++a) { w.qs[a][0] = buf.q_closest[a]; w.qs[a][1] = buf.q_any[a]; }
     uint32_t* rs = buf.counts;
     if ((e = hipMemsetAsync(rs, 0, wavefront_counter_bytes(), stream)) != hipSuccess) return e;
