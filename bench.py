@@ -62,18 +62,27 @@ def library_sha16():
     return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
 
 
-def frame_profile(workload):
-    """profiles/frame_<workload>.json (rocprofv3 PMC + kernel trace of one frame, tools/pmc_frame.sh) - but only when it
-    was measured on THIS build of the library; otherwise (None, reason): a counter file of another build says nothing
-    about the kernels that are running now."""
+def profile_key(workload, flags=()):
+    """Name of the counter file of a run: the workload plus every flag that changes what the kernels do or read
+    (`--ray-buffer`, `--literal`, `--no-grid`), e.g. cfg4+ray-buffer."""
+    return workload + "".join("+" + f.lstrip("-") for f in sorted(flags))
+
+
+def frame_profile(workload, flags=()):
+    """profiles/frame_<key>.json (rocprofv3 PMC + kernel trace of one frame, tools/pmc_frame.sh) - but only when it was
+    measured on THIS build of the library with THESE flags; otherwise (None, reason): a counter file of another build, or of
+    a run that read a ray buffer / tested every object, says nothing about the kernels that are running now."""
+    workload = profile_key(workload, flags)
     path = ROOT / "profiles" / f"frame_{workload}.json"
     if not path.exists():
-        return None, f"profiles/frame_{workload}.json not collected (tools/pmc_frame.sh {workload})"
+        return None, f"profiles/frame_{workload}.json not collected (tools/pmc_frame.sh {' --'.join(workload.split('+'))})"
     try:
         d = json.loads(path.read_text())
     except Exception as ex:  # noqa: BLE001
         return None, f"profiles/frame_{workload}.json unreadable: {ex}"
     have = library_sha16()
+    if sorted(d.get("flags", [])) != sorted(f.lstrip("-") for f in flags):
+        return None, f"profiles/frame_{workload}.json was measured with flags {d.get('flags', [])}: counters not quoted"
     if d.get("lib_sha16") != have:
         return None, (f"profiles/frame_{workload}.json was measured on library {d.get('lib_sha16')}, this run uses {have}: "
                       "counters not quoted (re-run tools/pmc_frame.sh)")
@@ -217,10 +226,55 @@ def measure_cfg3(device_index):
     else:
         roof["traffic_unavailable"] = why
     res = {"workload": desc, "value": st.rays_reference / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "render_wall_ms_incl_d2h": rt.render_host_ms(3), "setup_ms": rt.setup_times(),
            "rays_reference": int(st.rays_reference), "rays_traced": int(st.rays_traced), "hit_pixels": int(st.hit_pixels),
            "mrays_traced_per_s": st.rays_traced / dt / 1e6, "roofline": roof}
     rt.close()
     return res
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv, script=None, run=None):
+    """`bench.py --gpus N` started WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks ourselves -
+    `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process (never exec: a process that has
+    touched the GPU must not be replaced, and this one must not touch it at all) - relay rank 0's JSON line and return
+    the child's exit code. Refuses when the node has fewer than N GPUs, unless RT_BENCH_ONE_GPU=1 asks for the rehearsal
+    in which every rank shares GPU 0 (then over gloo unless RT_BENCH_BACKEND says otherwise)."""
+    import subprocess
+    import torch  # (import only: torch.cuda.device_count() does not initialise the GPU on this image)
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if env.get("RT_BENCH_ONE_GPU"):
+        env.setdefault("RT_BENCH_BACKEND", "gloo")
+    else:
+        have = torch.cuda.device_count()
+        if n > have:
+            print(f"bench.py: --gpus {n} but this node shows {have} GPU(s); RT_BENCH_ONE_GPU=1 rehearses the {n}-rank path on one",
+                  file=sys.stderr)
+            return 2
+    env["RT_BENCH_LAUNCHER"] = "self"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), str(script or Path(__file__).resolve())] + list(argv)
+    res = (run or subprocess.run)(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for cand in (res.stdout or "").splitlines():
+        cand = cand.strip()
+        if cand.startswith("{") and '"metric"' in cand:
+            line = cand
+    if line is not None:
+        print(line, flush=True)
+    elif res.returncode == 0:
+        print("bench.py: the ranks exited cleanly but printed no result line", file=sys.stderr)
+        return 3
+    assert not torch.cuda.is_initialized(), "the launching process must not touch the GPU"
+    return res.returncode
 
 
 def main():
@@ -237,6 +291,9 @@ def main():
     ap.add_argument("--ray-buffer", action="store_true", help="read primary rays from an uploaded buffer instead of in-kernel generation")
     ap.add_argument("--no-grid", action="store_true", help="large scenes: test every object for every ray (brute-force traversal, the VALU-roofline kernel)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -256,8 +313,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    if args.gpus != world:  # a launcher started a different number of ranks than --gpus says: the line would lie about N
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        sys.exit(2)
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -278,8 +337,12 @@ def main():
     # (distributed.FrameGather, pipelined mode; all of it inside the timed region, which ends with a device-wide sync).
     # RT_BENCH_PIPELINE=0: render, exchange, assemble one after the other. The gloo rehearsal stages through host memory anyway.
     # RT_BENCH_PIPELINE=force: also in the rehearsal (the same code path end to end on a one-GPU box).
-    _pl = os.environ.get("RT_BENCH_PIPELINE", "1")
-    pipeline = world > 1 and ((dist.get_backend() == "nccl" and _pl != "0") or _pl == "force")
+    # OPT-IN (RT_BENCH_PIPELINE=1) until the pipelined exchange has run once over RCCL on two real GPUs: the one-GPU gloo
+    # rehearsal blocks the host in .cpu() / req.wait() and so cannot show a stream-ordering stall.
+    _pl = os.environ.get("RT_BENCH_PIPELINE", "0")
+    pipeline = world > 1 and ((dist.get_backend() == "nccl" and _pl == "1") or _pl == "force")
+    pipeline_why = ("RT_BENCH_PIPELINE=%s" % _pl) if pipeline else (
+        "synchronous exchange: the pipelined one is opt-in (RT_BENCH_PIPELINE=1) until it has been validated over RCCL on >= 2 GPUs")
 
     if crop is not None:
         rays = camera.crop_rays(W, H, *crop)
@@ -356,6 +419,16 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    # every rank's own share: device time of its kernels per frame (HIP events on its render stream)
+    share = torch.zeros(world, dtype=torch.float64, device=red_dev)
+    share[rank] = kernel_ms_sum / max(launches, 1)
+    if world > 1:
+        dist.all_reduce(share)
+    share_ms = [float(x) for x in share.tolist()]
+    # what the boundary's synchronous Render() costs a caller: kernels + blocking read-back into pinned host memory
+    # (OpenCLRaytracer.cpp:94), and the one-time set-up that sits outside every timer (its constructor's work, :13-74)
+    render_wall_ms = rt.rt.render_host_ms(3) if world == 1 else None
+    setup_ms = rt.rt.setup_times()
 
     if rank == 0:
         assert frame is not None and frame.shape[0] == n_rays
@@ -367,7 +440,8 @@ def main():
         local = rt.rt.local_rays
         alg_bytes = 16 * local + (32 * local if ray_source == "buffer" else 0) + 320 * len(objs) + 64 * len(lights)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        prof, prof_why = (frame_profile(args.workload) if world == 1 else (None, "counters are collected on one GPU"))
+        run_flags = [f for f, on in (("--ray-buffer", args.ray_buffer), ("--literal", args.literal), ("--no-grid", args.no_grid)) if on]
+        prof, prof_why = (frame_profile(args.workload, run_flags) if world == 1 else (None, "counters are collected on one GPU"))
         traffic = prof["hbm_bytes_per_launch"] if prof else None
         out = {
             "metric": "Mrays/s (primary+reflect+shadow) at 4096x4096, 1/2/4/8 GPU; max RGB diff vs ref",
@@ -387,7 +461,16 @@ def main():
             "rays_reference": rays_ref, "rays_traced": rays_act, "hit_pixels": hit_pixels,
             "mrays_traced_per_s": rays_act * steps / elapsed / 1e6,
             "library_sha16": library_sha16(),
+            "render_wall_ms_incl_d2h": render_wall_ms,
+            "setup_ms": setup_ms,
         }
+        if world > 1:
+            out["ranks_seen"] = dist.get_world_size()
+            out["launcher"] = os.environ.get("RT_BENCH_LAUNCHER", "external (torch.distributed.run)")
+            out["backend"] = dist.get_backend()
+            out["share_ms"] = {"max": max(share_ms), "min": min(share_ms), "per_rank": share_ms}
+            out["exchange_ms"] = max(0.0, ms_per_step - max(share_ms))  # what the gather adds to the slowest share
+            out["pipeline"] = {"on": bool(pipeline), "why": pipeline_note or pipeline_why}
         hbm = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                "traffic": traffic, "kernel_ms": kernel_ms, "algorithmic_bytes_per_launch": alg_bytes}
         if prof:
@@ -406,7 +489,7 @@ def main():
             culled = not (args.no_grid or args.literal)
             out["roofline"] = {"bound": "valu", "achieved": valu / 1e12, "peak": VALU_PEAK_LANE_OPS * world / 1e12,
                                "unit": "T lane-instr/s", "frac": valu / (VALU_PEAK_LANE_OPS * world), "traffic": traffic,
-                               "kernel": ("rt::wf_trace_grid_persistent<closest|any> + rt::wf_trace_primary_tiles" if culled else
+                               "kernel": ("rt::wf_walk_blocks (closest-hit rays) + rt::wf_walk<any> (shadow rays) + rt::wf_trace_primary_tiles" if culled else
                                           "rt::wf_trace_closest + rt::wf_trace_any_slice") + " (+ wf_resume)",
                                "kernel_ms": kernel_ms, "object_tests": tests,
                                "tests_per_s": tests / (kernel_ms * 1e-3) if kernel_ms > 0 else 0.0, "hbm": hbm}
@@ -439,7 +522,7 @@ def main():
                 if world == 1 and not args.no_extra:
                     out["roofline"]["brute_force"] = measure_brute_force_window(local_rank, 4096)
         elif args.workload == "cfg5":
-            hbm["kernel"] = "rt::wf_trace_grid_persistent<closest|any> + rt::wf_trace_primary_tiles (+ wf_resume)"
+            hbm["kernel"] = "rt::wf_trace_grid_persistent<closest|any, triangles> + rt::wf_trace_primary_tiles (+ wf_resume)"
             hbm["note"] = ("triangles are this repo's extension (no reference semantics; SURVEY.md 8f5 defines no per-test work "
                            "figure for them): the mandated HBM figure only - the frame is bound by the grid walk's instruction "
                            "issue, like cfg4")
@@ -460,7 +543,11 @@ def main():
                 sample = camera.primary_rays(W, H, row_begin=H // 2 - rows // 2, row_end=H // 2 + rows // 2)
                 sdesc = f"centre {rows} rows of the {W}x{H} ray grid, same scene"
             out["cpu_baseline"] = cpu_baseline(objs, lights, sample, kernel, depth, sdesc)
-            out["cpu_backend"] = cpu_backend_baseline(objs, lights, sample, kernel, depth, sdesc)
+            try:  # (an optional baseline must never cost the result line)
+                out["cpu_backend"] = cpu_backend_baseline(objs, lights, sample, kernel, depth, sdesc)
+            except Exception as ex:  # noqa: BLE001
+                out["cpu_backend"] = None
+                out["cpu_backend_unavailable"] = f"{type(ex).__name__}: {ex}"
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))

@@ -40,7 +40,13 @@
 extern "C" {
 #endif
 
-#define RT_ABI_VERSION 1
+/* Version history:
+ *   1  round 1-2.
+ *   2  rt_render_device(ctx, out, NULL) means the LEGACY DEFAULT stream (it was the context's private stream in early
+ *      builds of version 1); rt_get_setup_times; the multi-device entry points rt_create_multi / rt_render_multi /
+ *      rt_render_multi_device / rt_multi_context / rt_destroy_multi. A caller built against version 1 keeps working:
+ *      no existing signature or struct changed. */
+#define RT_ABI_VERSION 2
 
 typedef struct rt_context rt_context;
 
@@ -141,7 +147,45 @@ int rt_get_stats(rt_context* ctx, rt_stats_t* stats);
 int rt_timing_reset(rt_context* ctx);
 int rt_timing_summary(rt_context* ctx, double* sum_ms, uint32_t* launches);
 
+/* One-time host-side work that sits OUTSIDE every render timer (the reference's equivalent is its constructor,
+ * OpenCLRaytracer.cpp:13-74): milliseconds of wall clock spent in rt_create and, for the per-camera screen tiles and the
+ * large-scene path's state buffers, in the first render. */
+typedef struct rt_setup_times_t {
+    double create_ms;        /* rt_create as a whole                                                          */
+    double upload_ms;        /* record re-pack + uploads (objects, lights, rays)                               */
+    double grid_ms;          /* conservative grid + the record table of the unified walk (0 for small scenes)  */
+    double blocks_ms;        /* the closest-hit walk's coarse grid of 32-byte blocks                           */
+    double light_tiles_ms;   /* light tiles of the last positional light                                       */
+    double screen_tiles_ms;  /* per-camera screen tiles (first render after rt_create / rt_set_camera)         */
+    double buffers_ms;       /* large-scene path: pixel state + queues allocation (first render)               */
+} rt_setup_times_t;
+int rt_get_setup_times(rt_context* ctx, rt_setup_times_t* times);
+
 void rt_destroy(rt_context* ctx);
+
+/* ---- several GPUs from one process ------------------------------------------------------------------------------------
+ * `new HIPRaytracer(objects, lights, rays, MAX_BOUNCES)` on a multi-GPU node (north_star: "row-tiles across the 8 GPUs of
+ * one node"; the reference drives exactly one device, OpenCLRaytracer.cpp:36-44). rt_create_multi builds one context per
+ * entry of `devices` (the same ordinal may appear more than once: a rehearsal on fewer GPUs), each with
+ * rt_set_shard(tile_rays, r, n_devices): interleaved tiles of `tile_rays` consecutive rays (a row-tile = tile_rows * width).
+ * A render runs every context on a host thread of its own, on its own device and stream; each context's packed tiles are
+ * then copied device-to-device (peer access where the runtime grants it) straight to their final offsets in the frame held
+ * on devices[0] - the gather of SURVEY.md 8e without a second process or a collective library.
+ *   rt_render_multi         synchronous, like rt_render: the whole frame (n_rays elements) in a host buffer owned by `m`
+ *   rt_render_multi_device  the whole frame into caller-provided memory ON devices[0] (n_rays elements, padded up to whole
+ *                           tiles: rt_multi_frame_elems()); returns when the frame is complete
+ *   rt_multi_context        the r-th context (rt_count_rays / rt_get_stats / rt_timing_* per shard) */
+typedef struct rt_multi rt_multi;
+int rt_create_multi(rt_multi** m, const void* objs, uint32_t n_objs, const void* lights, uint32_t n_lights,
+                    const void* rays, uint64_t n_rays, uint32_t max_bounces, int kernel,
+                    const int* devices, uint32_t n_devices, uint64_t tile_rays, uint32_t flags);
+int rt_set_camera_multi(rt_multi* m, uint32_t width, uint32_t height, float z);
+uint64_t rt_multi_frame_elems(const rt_multi* m);
+int rt_render_multi(rt_multi* m, const float** out);
+int rt_render_multi_device(rt_multi* m, void* d_frame);
+rt_context* rt_multi_context(rt_multi* m, uint32_t r);
+const char* rt_multi_last_error(const rt_multi* m);
+void rt_destroy_multi(rt_multi* m);
 /* Message of the last failure on this context (ctx may be NULL for a failed rt_create). */
 const char* rt_last_error(const rt_context* ctx);
 int rt_abi_version(void);

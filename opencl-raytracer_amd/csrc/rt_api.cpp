@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -16,11 +17,22 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
 
 thread_local std::string g_create_error;
+
+struct StopWatch {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double lap_ms() {
+        const auto t1 = std::chrono::steady_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        t0 = t1;
+        return ms;
+    }
+};
 
 constexpr uint32_t kTimingSlots = 256;
 
@@ -98,6 +110,8 @@ struct rt_context {
 
     rt::Counters* d_counters = nullptr;
     rt::Counters counters = {};
+
+    rt_setup_times_t setup = {};
 
     hipEvent_t ev_begin[kTimingSlots];
     hipEvent_t ev_end[kTimingSlots];
@@ -533,8 +547,11 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     c->last_wavefront = use_wavefront(c);
     c->last_rounds = 0;
     if (c->last_wavefront) {  // one-time host-side set-up (buffers, per-camera screen tiles) stays outside the timed region
+        StopWatch sw;
+        const bool had_buffers = c->wf.capacity >= c->n_local && c->wf.state;
         int rc = ensure_wavefront(c);
         if (rc) return rc;
+        if (!had_buffers) c->setup.buffers_ms += sw.lap_ms();
         // a first-round wave is an 8 x 8 block of pixels (work-items in tile order) or 64 pixels of one row: the tile lists follow
         const uint32_t col_shift = p.wf_tile_order ? 3u : 6u;
         if (c->tiles_dirty || c->tiles_built_for != col_shift) {
@@ -547,6 +564,8 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
                 if (rc) return rc;
             }
             c->tiles_built_for = col_shift;
+            RT_HIP(c, hipStreamSynchronize(stream));
+            c->setup.screen_tiles_ms += sw.lap_ms();
         }
         c->wf.tiles = c->tiles;
     }
@@ -1175,8 +1194,10 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     g.pretest_alpha = std::nextafter((float)(6e-6 * K2 + 8e-6), std::numeric_limits<float>::infinity());
     g.enabled = 1u;
     if (!c->has_triangles) {
+        StopWatch sw;
         const int rc = build_walk_blocks(c, n, sph, rg, cell, glo, ghi, K2);
         if (rc != RT_OK) return rc;
+        c->setup.blocks_ms = sw.lap_ms();
     }
     c->h_grid_spheres.resize(4 * (size_t)n);
     for (uint32_t i = 0; i < n; ++i) {
@@ -1204,7 +1225,23 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
     const double L[3] = {lp[0], lp[1], lp[2]};
     const uint32_t n = c->n_objs;
     const double inf = std::numeric_limits<double>::infinity();
-    constexpr double kPad = 1e-3, kFront = 0.05;
+    // The fp32 shadow ray - start fl(P + 0.01 n), direction fl(L - P) - misses the exact line through the light by about
+    // 1e-7 x (the coordinates involved + the distance to the light): the pad every registration sphere gets for it, and the
+    // absolute slack of the kernels' distance cut, scale with the scene like the grid's own radii do (a fixed
+    // 1e-3 is too little once coordinates or light distances reach 1e4).
+    double coord_max = std::sqrt(L[0] * L[0] + L[1] * L[1] + L[2] * L[2]), reach_max = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const double r = c->h_grid_spheres[4 * i + 3];
+        if (!(r >= 0) || r == inf) continue;
+        double cl = 0, dl = 0;
+        for (int a = 0; a < 3; ++a) {
+            cl += c->h_grid_spheres[4 * i + a] * c->h_grid_spheres[4 * i + a];
+            dl += (c->h_grid_spheres[4 * i + a] - L[a]) * (c->h_grid_spheres[4 * i + a] - L[a]);
+        }
+        coord_max = std::max(coord_max, std::sqrt(cl) + r);
+        reach_max = std::max(reach_max, std::sqrt(dl) + r);
+    }
+    const double kPad = std::max(1e-3, 4e-7 * (2.0 * coord_max + reach_max)), kFront = 0.05;
     // projection axis: every registered object strictly in front of the plane through the light
     int best_axis = -1;
     double best_sign = 0, best_clear = 0;
@@ -1334,6 +1371,7 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
     lt.ax = ax; lt.ay = ay; lt.az = az;
     lt.sx = 1.f; lt.sy = 1.f; lt.sz = (float)szn;
     lt.light = li;
+    lt.cut_pad = (float)std::max(1e-4, 4e-7 * (2.0 * coord_max + reach_max));
     lt.enabled = 1u;
     if (!c->h_walk.empty() && total) {  // the same lists as records of the unified walk, each tile's chained to its end
         const uint64_t base = c->h_walk.size() / 2;
@@ -1391,6 +1429,7 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
     c->n_local = n_rays;
     c->max_bounces = max_bounces;
 
+    StopWatch sw_total, sw;
     int rc = RT_OK;
     auto bail = [&](int code) {
         g_create_error = c->error;
@@ -1507,13 +1546,18 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         }
     }
 #undef RT_TRY
+    (void)hipDeviceSynchronize();
+    c->setup.upload_ms = sw.lap_ms();
     if (n_objs >= kWavefrontGridMinObjects || (flags & RT_FLAG_WAVEFRONT) || c->has_triangles) {
         rc = build_grid(c, static_cast<const rt_object_data*>(objs), n_objs);
         if (rc != RT_OK) return bail(rc);
+        c->setup.grid_ms = sw.lap_ms() - c->setup.blocks_ms;  // (build_grid ends with the block grid, which times itself)
         rc = build_light_tiles(c, static_cast<const rt_light*>(lights));
         if (rc != RT_OK) return bail(rc);
+        c->setup.light_tiles_ms = sw.lap_ms();
         rc = upload_walk_records(c);
         if (rc != RT_OK) return bail(rc);
+        c->setup.grid_ms += sw.lap_ms();
     }
     if (c->has_triangles && (!c->grid.enabled || (flags & (RT_FLAG_LITERAL | RT_FLAG_MONOLITHIC | RT_FLAG_NO_GRID)))) {
         fail(c, RT_ERR_INVALID_ARGUMENT,
@@ -1521,7 +1565,14 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
              "it needs affine instances, ray w = 1, and none of RT_FLAG_LITERAL / RT_FLAG_MONOLITHIC / RT_FLAG_NO_GRID");
         return bail(RT_ERR_INVALID_ARGUMENT);
     }
+    c->setup.create_ms = sw_total.lap_ms();
     *out_ctx = c;
+    return RT_OK;
+}
+
+int rt_get_setup_times(rt_context* c, rt_setup_times_t* t) {
+    if (!c || !t) return RT_ERR_INVALID_ARGUMENT;
+    *t = c->setup;
     return RT_OK;
 }
 
@@ -1710,6 +1761,193 @@ void rt_destroy(rt_context* c) {
     for (uint32_t i = 0; i < c->ev_end_made; ++i) (void)hipEventDestroy(c->ev_end[i]);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+}  // extern "C"
+
+// ---- several GPUs from one process (hip_raytracer.h: rt_create_multi ...) ------------------------------------------------
+struct rt_multi {
+    std::vector<rt_context*> ctx;
+    std::vector<int> devices;
+    std::vector<void*> d_local;      // per context: its packed tiles, on its own device
+    std::vector<char> peer_ok;       // per context: devices[0] and its device can address each other's memory
+    uint64_t n_rays = 0, tile_rays = 0, tiles = 0;
+    size_t elem = 16;
+    void* d_frame = nullptr;         // rt_render_multi's frame on devices[0] (whole tiles)
+    void* h_frame = nullptr;         // ... and its pinned host copy
+    std::string error;
+};
+
+namespace {
+
+thread_local std::string g_multi_error;
+
+int multi_fail(rt_multi* m, int code, const std::string& msg) {
+    if (m) m->error = msg;
+    else g_multi_error = msg;
+    return code;
+}
+
+// one shard: render on the context's own stream, then put its tiles where they belong in the frame on devices[0]
+int multi_render_shard(rt_multi* m, uint32_t r, void* d_frame, std::string& err) {
+    rt_context* c = m->ctx[r];
+    DeviceGuard guard(c->device);
+    if (!guard.ok) { err = std::string("hipSetDevice: ") + hipGetErrorString(guard.err); return RT_ERR_HIP; }
+    int rc = rt_render_device(c, m->d_local[r], c->stream);
+    if (rc != RT_OK) { err = c->error; return rc; }
+    const uint32_t n = (uint32_t)m->ctx.size();
+    const uint64_t mine = m->tiles / n + ((m->tiles % n) > r ? 1 : 0);
+    const size_t tile_bytes = (size_t)m->tile_rays * m->elem;
+    hipError_t e = hipSuccess;
+    if (mine) {
+        char* dst = static_cast<char*>(d_frame) + (size_t)r * tile_bytes;
+        if (c->device == m->devices[0] || m->peer_ok[r]) {
+            // tile j of this shard is tile j * n + r of the frame: one strided copy
+            e = hipMemcpy2DAsync(dst, (size_t)n * tile_bytes, m->d_local[r], tile_bytes, tile_bytes, (size_t)mine, hipMemcpyDeviceToDevice, c->stream);
+        } else {
+            for (uint64_t j = 0; j < mine && e == hipSuccess; ++j)
+                e = hipMemcpyPeerAsync(dst + (size_t)j * n * tile_bytes, m->devices[0], static_cast<char*>(m->d_local[r]) + (size_t)j * tile_bytes,
+                                       c->device, tile_bytes, c->stream);
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { err = std::string("tile placement: ") + hipGetErrorString(e); return RT_ERR_HIP; }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_multi_last_error(const rt_multi* m) { return m ? m->error.c_str() : g_multi_error.c_str(); }
+
+void rt_destroy_multi(rt_multi* m) {
+    if (!m) return;
+    for (size_t r = 0; r < m->ctx.size(); ++r) {
+        if (m->ctx[r] && r < m->d_local.size() && m->d_local[r]) {
+            DeviceGuard guard(m->ctx[r]->device);
+            (void)hipFree(m->d_local[r]);
+        }
+        rt_destroy(m->ctx[r]);
+    }
+    if (!m->devices.empty()) {
+        DeviceGuard guard(m->devices[0]);
+        if (m->d_frame) (void)hipFree(m->d_frame);
+        if (m->h_frame) (void)hipHostFree(m->h_frame);
+    }
+    delete m;
+}
+
+int rt_create_multi(rt_multi** out, const void* objs, uint32_t n_objs, const void* lights, uint32_t n_lights, const void* rays,
+                    uint64_t n_rays, uint32_t max_bounces, int kernel, const int* devices, uint32_t n_devices, uint64_t tile_rays,
+                    uint32_t flags) {
+    g_multi_error.clear();
+    if (!out) return multi_fail(nullptr, RT_ERR_INVALID_ARGUMENT, "m is NULL");
+    *out = nullptr;
+    if (!devices || n_devices == 0 || n_devices > 64) return multi_fail(nullptr, RT_ERR_INVALID_ARGUMENT, "need 1..64 device ordinals");
+    rt_multi* m = new (std::nothrow) rt_multi();
+    if (!m) return multi_fail(nullptr, RT_ERR_OUT_OF_MEMORY, "host allocation failed");
+    m->devices.assign(devices, devices + n_devices);
+    m->ctx.assign(n_devices, nullptr);
+    m->d_local.assign(n_devices, nullptr);
+    m->peer_ok.assign(n_devices, 0);
+    m->n_rays = n_rays;
+    m->elem = kernel == RT_KERNEL_HITTEST ? sizeof(float) : 4 * sizeof(float);
+    // the contexts are built side by side: each one's grid / tile builders run on a host thread of their own
+    std::vector<int> rcs(n_devices, RT_OK);
+    std::vector<std::string> errs(n_devices);
+    {
+        std::vector<std::thread> workers;
+        for (uint32_t r = 0; r < n_devices; ++r)
+            workers.emplace_back([&, r]() {
+                rcs[r] = rt_create(&m->ctx[r], objs, n_objs, lights, n_lights, rays, n_rays, max_bounces, kernel, m->devices[r], flags);
+                if (rcs[r] != RT_OK) errs[r] = rt_last_error(nullptr);
+            });
+        for (std::thread& t : workers) t.join();
+    }
+    for (uint32_t r = 0; r < n_devices; ++r)
+        if (rcs[r] != RT_OK) {
+            const int rc = multi_fail(nullptr, rcs[r], "context " + std::to_string(r) + " (device " + std::to_string(m->devices[r]) + "): " + errs[r]);
+            rt_destroy_multi(m);
+            return rc;
+        }
+    // tiles: the caller's, or row-tiles of 16 rows when the rays are the pinhole grid, else 65 536 rays
+    if (tile_rays == 0) {
+        const rt_context* c0 = m->ctx[0];
+        tile_rays = c0->pinhole && c0->width ? 16ull * c0->width : 65536ull;
+    }
+    m->tile_rays = tile_rays;
+    m->tiles = (n_rays + tile_rays - 1) / tile_rays;
+    for (uint32_t r = 0; r < n_devices; ++r) {
+        rt_context* c = m->ctx[r];
+        int rc = rt_set_shard(c, tile_rays, r, n_devices);
+        hipError_t e = hipSuccess;
+        if (rc == RT_OK) {
+            DeviceGuard guard(c->device);
+            const size_t bytes = (size_t)c->n_local * m->elem;
+            e = hipMalloc(&m->d_local[r], bytes ? bytes : 16);
+            if (e == hipSuccess && c->device != m->devices[0]) {  // both directions; "already enabled" is fine
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, c->device, m->devices[0]) == hipSuccess && can) {
+                    const hipError_t pe = hipDeviceEnablePeerAccess(m->devices[0], 0);
+                    if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) m->peer_ok[r] = 1;
+                    (void)hipGetLastError();
+                }
+            }
+        }
+        if (rc != RT_OK || e != hipSuccess) {
+            const int code = multi_fail(nullptr, rc != RT_OK ? rc : RT_ERR_HIP, rc != RT_OK ? c->error : std::string("hipMalloc: ") + hipGetErrorString(e));
+            rt_destroy_multi(m);
+            return code;
+        }
+    }
+    *out = m;
+    return RT_OK;
+}
+
+int rt_set_camera_multi(rt_multi* m, uint32_t width, uint32_t height, float z) {
+    if (!m) return RT_ERR_INVALID_ARGUMENT;
+    for (rt_context* c : m->ctx) {
+        const int rc = rt_set_camera(c, width, height, z);
+        if (rc != RT_OK) return multi_fail(m, rc, c->error);
+    }
+    return RT_OK;
+}
+
+uint64_t rt_multi_frame_elems(const rt_multi* m) { return m ? m->tiles * m->tile_rays : 0; }
+
+rt_context* rt_multi_context(rt_multi* m, uint32_t r) { return (m && r < m->ctx.size()) ? m->ctx[r] : nullptr; }
+
+int rt_render_multi_device(rt_multi* m, void* d_frame) {
+    if (!m) return RT_ERR_INVALID_ARGUMENT;
+    if (!d_frame && m->n_rays) return multi_fail(m, RT_ERR_INVALID_ARGUMENT, "d_frame is NULL");
+    const uint32_t n = (uint32_t)m->ctx.size();
+    std::vector<int> rcs(n, RT_OK);
+    std::vector<std::string> errs(n);
+    std::vector<std::thread> workers;
+    for (uint32_t r = 1; r < n; ++r) workers.emplace_back([&, r]() { rcs[r] = multi_render_shard(m, r, d_frame, errs[r]); });
+    rcs[0] = multi_render_shard(m, 0, d_frame, errs[0]);
+    for (std::thread& t : workers) t.join();
+    for (uint32_t r = 0; r < n; ++r)
+        if (rcs[r] != RT_OK) return multi_fail(m, rcs[r], "shard " + std::to_string(r) + ": " + errs[r]);
+    return RT_OK;
+}
+
+int rt_render_multi(rt_multi* m, const float** out) {
+    if (!m || !out) return RT_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(m->devices[0]);
+    if (!guard.ok) return multi_fail(m, RT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
+    const size_t frame_bytes = (size_t)rt_multi_frame_elems(m) * m->elem, want = (size_t)m->n_rays * m->elem;
+    hipError_t e = hipSuccess;
+    if (!m->d_frame) e = hipMalloc(&m->d_frame, frame_bytes ? frame_bytes : 16);
+    if (e == hipSuccess && !m->h_frame) e = hipHostMalloc(&m->h_frame, want ? want : 16, hipHostMallocDefault);
+    if (e != hipSuccess) return multi_fail(m, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, std::string("frame buffers: ") + hipGetErrorString(e));
+    const int rc = rt_render_multi_device(m, m->d_frame);
+    if (rc != RT_OK) return rc;
+    if (want) e = hipMemcpy(m->h_frame, m->d_frame, want, hipMemcpyDeviceToHost);  // Render() is synchronous (OpenCLRaytracer.cpp:94)
+    if (e != hipSuccess) return multi_fail(m, RT_ERR_HIP, std::string("read-back: ") + hipGetErrorString(e));
+    *out = static_cast<const float*>(m->h_frame);
+    return RT_OK;
 }
 
 }  // extern "C"

@@ -151,12 +151,13 @@ struct LightTiles {
     uint32_t light;                            // index of the light the structure is for
     uint32_t enabled;
     uint32_t walk_base;                        // entry e of a tile = record walk_base + e of GridDesc::walk_rec (0: not built)
+    float cut_pad;                             // absolute slack of the distance cut: the rounding of origin - light (scales with the coordinates)
 };
 
 // tile of the ray whose ORIGIN is `s` (any point of the line through the light does): false = no object in that direction
 __device__ __forceinline__ bool light_tile_of(const LightTiles& lt, float sx, float sy, float sz, uint32_t& tile, float& dist) {
     const float p[3] = {sx - lt.lx, sy - lt.ly, sz - lt.lz};
-    dist = __builtin_sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) * 1.000001f + 1.0e-4f;  // origin <-> light, rounded up
+    dist = __builtin_sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) * 1.000001f + lt.cut_pad;  // origin <-> light, rounded up
     const float qx = lt.sx * (lt.ax == 0u ? p[0] : (lt.ax == 1u ? p[1] : p[2]));
     const float qy = lt.sy * (lt.ay == 0u ? p[0] : (lt.ay == 1u ? p[1] : p[2]));
     const float qz = lt.sz * (lt.az == 0u ? p[0] : (lt.az == 1u ? p[1] : p[2]));

@@ -2065,6 +2065,10 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
             if (nc_max + na_max == 0) break;
         }
         if (use_grid) {
+            // (wf_finish resumes pixels from their stored phase words and rays: never as a first round - with a batch of one
+            //  round, RT_WF_BATCH=1, `w` would still carry the first round's flags here)
+            w.first_round = 0u;
+            w.identity_queue = 0u;
             hipLaunchKernelGGL((wf_finish<KERNEL, FUSED>), grid_for(finish_threshold ? finish_threshold : 1), dim3(256), 0, stream, w);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }

@@ -149,9 +149,9 @@ class FrameGather:
             for req in self.pending[slot] or ():
                 req.wait()
             self.pending[slot] = None
-        self.render_stream.synchronize()
-        if self.place_stream is not None:
-            self.place_stream.synchronize()
+        # (over RCCL req.wait() only makes the CURRENT stream wait for the transfer: a host-side guarantee needs the
+        #  device-wide synchronisation - a peer's last isend may still be in flight behind the two streams above)
+        torch.cuda.synchronize(self.render_stream.device)
 
     def gather(self):
         """Returns the assembled frame on rank `dst`, None elsewhere."""

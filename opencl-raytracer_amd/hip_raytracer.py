@@ -29,7 +29,9 @@ FLAG_UNFUSED, FLAG_LITERAL, FLAG_NO_RAYGEN, FLAG_WAVEFRONT, FLAG_MONOLITHIC, FLA
 EXPORTS = [
     "rt_abi_version", "rt_create", "rt_set_camera", "rt_set_shard", "rt_local_rays", "rt_render",
     "rt_render_device", "rt_set_aux_device", "rt_render_aux", "rt_count_rays", "rt_get_stats",
-    "rt_timing_reset", "rt_timing_summary", "rt_destroy", "rt_last_error",
+    "rt_timing_reset", "rt_timing_summary", "rt_destroy", "rt_last_error", "rt_get_setup_times",
+    "rt_create_multi", "rt_set_camera_multi", "rt_multi_frame_elems", "rt_render_multi", "rt_render_multi_device",
+    "rt_multi_context", "rt_multi_last_error", "rt_destroy_multi",
 ]
 
 
@@ -46,6 +48,14 @@ class RTStats(ctypes.Structure):
         ("width", ctypes.c_uint32), ("height", ctypes.c_uint32), ("local_rays", ctypes.c_uint64),
         ("wavefront", ctypes.c_uint32), ("rounds", ctypes.c_uint32), ("object_tests", ctypes.c_uint64),
     ]
+
+
+class RTSetupTimes(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in ("create_ms", "upload_ms", "grid_ms", "blocks_ms", "light_tiles_ms",
+                                                "screen_tiles_ms", "buffers_ms")]
+
+    def as_dict(self):
+        return {n: float(getattr(self, n)) for n, _ in self._fields_}
 
 
 _lib = None
@@ -92,6 +102,24 @@ def load_library(path: os.PathLike | None = None) -> ctypes.CDLL:
     lib.rt_destroy.argtypes = [vp]
     lib.rt_last_error.restype = ctypes.c_char_p
     lib.rt_last_error.argtypes = [vp]
+    lib.rt_get_setup_times.restype = i32
+    lib.rt_get_setup_times.argtypes = [vp, ctypes.POINTER(RTSetupTimes)]
+    lib.rt_create_multi.restype = i32
+    lib.rt_create_multi.argtypes = [ctypes.POINTER(vp), vp, u32, vp, u32, vp, u64, u32, i32, ctypes.POINTER(i32), u32, u64, u32]
+    lib.rt_set_camera_multi.restype = i32
+    lib.rt_set_camera_multi.argtypes = [vp, u32, u32, ctypes.c_float]
+    lib.rt_multi_frame_elems.restype = u64
+    lib.rt_multi_frame_elems.argtypes = [vp]
+    lib.rt_render_multi.restype = i32
+    lib.rt_render_multi.argtypes = [vp, ctypes.POINTER(ctypes.POINTER(ctypes.c_float))]
+    lib.rt_render_multi_device.restype = i32
+    lib.rt_render_multi_device.argtypes = [vp, vp]
+    lib.rt_multi_context.restype = vp
+    lib.rt_multi_context.argtypes = [vp, u32]
+    lib.rt_multi_last_error.restype = ctypes.c_char_p
+    lib.rt_multi_last_error.argtypes = [vp]
+    lib.rt_destroy_multi.restype = None
+    lib.rt_destroy_multi.argtypes = [vp]
     if path is None:
         _lib = lib
     return lib
@@ -180,6 +208,25 @@ class HIPRaytracer:
         arr = np.ctypeslib.as_array(out, shape=(n * self.elem_floats,)).copy()
         return arr.reshape(n, 4) if self.elem_floats == 4 else arr
 
+    def render_host_ms(self, frames: int = 3) -> float:
+        """Wall time of the synchronous Render() through the boundary - kernels + the blocking read-back into the
+        context's pinned host buffer (OpenCLRaytracer.cpp:94) - without this wrapper's numpy copy: best of `frames`."""
+        import time
+        out = ctypes.POINTER(ctypes.c_float)()
+        best = None
+        for _ in range(max(1, frames)):
+            t0 = time.perf_counter()
+            self._check(self._lib.rt_render(self._ctx, ctypes.byref(out)))
+            dt = (time.perf_counter() - t0) * 1e3
+            best = dt if best is None else min(best, dt)
+        return best
+
+    def setup_times(self) -> dict:
+        """One-time host-side work outside every render timer (rt_setup_times_t), milliseconds."""
+        t = RTSetupTimes()
+        self._check(self._lib.rt_get_setup_times(self._ctx, ctypes.byref(t)))
+        return t.as_dict()
+
     # -- extensions over the reference interface -----------------------------------------------
     def set_shard(self, tile_rays: int, rank: int, world: int):
         self._check(self._lib.rt_set_shard(self._ctx, int(tile_rays), int(rank), int(world)))
@@ -214,3 +261,83 @@ class HIPRaytracer:
         n = ctypes.c_uint32(0)
         self._check(self._lib.rt_timing_summary(self._ctx, ctypes.byref(total), ctypes.byref(n)))
         return float(total.value), int(n.value)
+
+
+class MultiHIPRaytracer:
+    """IRaytracer backend for several GPUs driven from ONE process through the C ABI (rt_create_multi): one context and one
+    host thread per device, interleaved row-tiles, tiles copied device-to-device to their place in the frame on
+    devices[0]. `devices` may repeat an ordinal (rehearsal on fewer GPUs). The torch.distributed flavour - one process
+    per GPU, RCCL exchange - is distributed.ShardedHIPRaytracer."""
+
+    def __init__(self, objects, lights, rays, MAX_BOUNCES: int = 0, *, devices=(0,), kernel="shade_and_reflect",
+                 camera: tuple[int, int, float] | None = None, tile_rays: int = 0, fused: bool = True, literal: bool = False,
+                 grid: bool = True):
+        self._lib = load_library()
+        self._m = ctypes.c_void_p()
+        objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+        lights = np.ascontiguousarray(lights, dtype=LIGHT_DTYPE)
+        self.kernel = KERNELS[kernel] if isinstance(kernel, str) else int(kernel)
+        flags = (0 if fused else FLAG_UNFUSED) | (FLAG_LITERAL if literal else 0) | (0 if grid else FLAG_NO_GRID)
+        if rays is not None:
+            rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+            n_rays = int(rays.shape[0])
+        else:
+            if camera is None:
+                raise ValueError("either rays or camera=(width, height, z) is required")
+            n_rays = int(camera[0]) * int(camera[1])
+            if tile_rays == 0:
+                tile_rays = 16 * int(camera[0])
+        devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+        rc = self._lib.rt_create_multi(ctypes.byref(self._m), _ptr(objects), int(objects.shape[0]), _ptr(lights),
+                                       int(lights.shape[0]), _ptr(rays), n_rays, int(MAX_BOUNCES), self.kernel, devs,
+                                       len(devices), int(tile_rays), flags)
+        if rc != 0:
+            msg = self._lib.rt_multi_last_error(None)
+            self._m = ctypes.c_void_p()
+            raise RTError(rc, msg.decode() if msg else "rt_create_multi failed")
+        if camera is not None:
+            self._check(self._lib.rt_set_camera_multi(self._m, int(camera[0]), int(camera[1]), float(camera[2])))
+        self.n_rays = n_rays
+        self.n_devices = len(devices)
+
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self._lib.rt_multi_last_error(self._m)
+            raise RTError(rc, msg.decode() if msg else "")
+
+    @property
+    def elem_floats(self) -> int:
+        return 1 if self.kernel == KERNEL_HITTEST else 4
+
+    @property
+    def frame_elems(self) -> int:
+        return int(self._lib.rt_multi_frame_elems(self._m))
+
+    def Render(self) -> np.ndarray:
+        out = ctypes.POINTER(ctypes.c_float)()
+        self._check(self._lib.rt_render_multi(self._m, ctypes.byref(out)))
+        if self.n_rays == 0:
+            return np.zeros((0, 4) if self.elem_floats == 4 else (0,), dtype=np.float32)
+        arr = np.ctypeslib.as_array(out, shape=(self.n_rays * self.elem_floats,)).copy()
+        return arr.reshape(self.n_rays, 4) if self.elem_floats == 4 else arr
+
+    def render_device(self, d_frame_ptr: int):
+        """The whole frame into device memory on devices[0] (frame_elems elements); returns when it is complete."""
+        self._check(self._lib.rt_render_multi_device(self._m, ctypes.c_void_p(d_frame_ptr)))
+
+    def close(self):
+        if getattr(self, "_m", None) and self._m.value:
+            self._lib.rt_destroy_multi(self._m)
+            self._m = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

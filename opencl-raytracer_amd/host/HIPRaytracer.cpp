@@ -55,16 +55,40 @@ HIPRaytracer::HIPRaytracer(const std::vector<ObjectData>& objects_, const std::v
     if (rc != RT_OK) throw std::runtime_error(std::string("HIPRaytracer: ") + rt_last_error(nullptr));
 }
 
-HIPRaytracer::~HIPRaytracer() { rt_destroy(ctx); }
+HIPRaytracer::HIPRaytracer(const std::vector<ObjectData>& objects_, const std::vector<Light>& lights_,
+                           const std::vector<Ray3D>& rays_, unsigned int MAX_BOUNCES, const std::vector<int>& devices,
+                           unsigned int flags, int kernel)
+    : IRaytracer(objects_, lights_, rays_) {
+    std::vector<rt_object_data> objs;
+    objs.reserve(objects.size());
+    for (const ObjectData& o : objects) objs.push_back(to_device(o));
+    std::vector<rt_light> ls;
+    ls.reserve(lights.size());
+    for (const Light& l : lights) ls.push_back(to_device(l));
+    // tile_rays = 0: row-tiles of 16 rows when the rays are the pinhole grid, else 65 536 rays
+    const int rc = rt_create_multi(&multi, objs.data(), static_cast<uint32_t>(objs.size()), ls.data(), static_cast<uint32_t>(ls.size()),
+                                   rays.data(), rays.size(), MAX_BOUNCES, kernel, devices.data(), static_cast<uint32_t>(devices.size()), 0, flags);
+    if (rc != RT_OK) throw std::runtime_error(std::string("HIPRaytracer: ") + rt_multi_last_error(nullptr));
+}
+
+HIPRaytracer::~HIPRaytracer() {
+    rt_destroy(ctx);
+    rt_destroy_multi(multi);
+}
 
 cl_float4* HIPRaytracer::Render() {
     const float* out = nullptr;
+    if (multi) {
+        if (rt_render_multi(multi, &out) != RT_OK) throw std::runtime_error(std::string("HIPRaytracer::Render: ") + rt_multi_last_error(multi));
+        return reinterpret_cast<cl_float4*>(const_cast<float*>(out));
+    }
     if (rt_render(ctx, &out) != RT_OK) throw std::runtime_error(std::string("HIPRaytracer::Render: ") + rt_last_error(ctx));
     return reinterpret_cast<cl_float4*>(const_cast<float*>(out));
 }
 
 rt_stats_t HIPRaytracer::Stats() {
     rt_stats_t s;
-    if (rt_get_stats(ctx, &s) != RT_OK) throw std::runtime_error(std::string("HIPRaytracer::Stats: ") + rt_last_error(ctx));
+    rt_context* c = multi ? rt_multi_context(multi, 0) : ctx;  // (several GPUs: the first shard's)
+    if (rt_get_stats(c, &s) != RT_OK) throw std::runtime_error(std::string("HIPRaytracer::Stats: ") + rt_last_error(c));
     return s;
 }

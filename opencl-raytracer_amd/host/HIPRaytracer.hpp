@@ -19,6 +19,12 @@ public:
     HIPRaytracer(const std::vector<ObjectData>& objects, const std::vector<Light>& lights, const std::vector<Ray3D>& rays,
                  unsigned int MAX_BOUNCES, int device = 0, unsigned int flags = 0,
                  int kernel = RT_KERNEL_SHADE_AND_REFLECT);
+    // The same raytracer over several GPUs of one node (north_star: row-tiles across the GPUs, gathered on the first):
+    // one entry of `devices` per shard (an ordinal may repeat: a rehearsal on fewer GPUs), interleaved row-tiles,
+    // Render() returns the whole frame as before. rt_create_multi / rt_render_multi of the C ABI.
+    HIPRaytracer(const std::vector<ObjectData>& objects, const std::vector<Light>& lights, const std::vector<Ray3D>& rays,
+                 unsigned int MAX_BOUNCES, const std::vector<int>& devices, unsigned int flags = 0,
+                 int kernel = RT_KERNEL_SHADE_AND_REFLECT);
     ~HIPRaytracer() override;
     HIPRaytracer(const HIPRaytracer&) = delete;
     HIPRaytracer& operator=(const HIPRaytracer&) = delete;
@@ -32,4 +38,5 @@ public:
 
 private:
     rt_context* ctx = nullptr;
+    rt_multi* multi = nullptr;   // set instead of ctx by the several-GPU constructor
 };

@@ -62,6 +62,12 @@ int main(int argc, char** argv) {
         std::printf("sum %.6f %.6f %.6f\n", sum[0], sum[1], sum[2]);
         std::printf("pinhole %u %u %u\n", st.pinhole, st.width, st.height);
         std::printf("kernel_ms %.4f\n", st.last_kernel_ms);
+        if (argc > 3) {  // argv[3] = n: the same frame from n shards (contexts on device 0) through the several-GPU constructor
+            const int n = std::atoi(argv[3]);
+            std::unique_ptr<IRaytracer> sharded(new HIPRaytracer(objects, lights, rays, 3, std::vector<int>((size_t)n, 0)));
+            cl_float4* frame = sharded->Render();
+            std::printf("multi_equal %d\n", std::memcmp(frame, pixels, sizeof(cl_float4) * (size_t)width * height) == 0);
+        }
         if (argc > 1) {  // dump raw RGBA for comparison
             FILE* f = std::fopen(argv[1], "wb");
             if (!f) return 3;

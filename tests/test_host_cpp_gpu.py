@@ -19,9 +19,10 @@ def test_cpp_host_renders_config1(tmp_path):
         __graft_entry__.build()
     dump = tmp_path / "frame.bin"
     zbits = np.float32(camera.camera_z(256)).view(np.uint32)  # same camera z as the fixture's rays, bit for bit
-    res = subprocess.run([str(BIN), str(dump), f"{int(zbits):08x}"], capture_output=True, text=True, timeout=300)
+    res = subprocess.run([str(BIN), str(dump), f"{int(zbits):08x}", "3"], capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout + res.stderr
     lines = dict(l.split(" ", 1) for l in res.stdout.strip().splitlines())
+    assert lines["multi_equal"] == "1"          # HIPRaytracer(..., devices = {0, 0, 0}): three shards, the same frame bit for bit
     assert lines["same_buffer"] == "1"          # Render() returns the same backend-owned buffer every frame
     assert lines["nonblack"] == "1565"          # config-1 known answer
     assert lines["pinhole"] == "1 256 256"      # the uploaded ray grid was recognised and regenerated in-kernel

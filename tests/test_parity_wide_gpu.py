@@ -269,3 +269,58 @@ def test_light_tiles_for_a_last_light_on_every_side_of_the_cloud(axis, sign, res
     assert np.array_equal(outs[True].view(np.uint32), outs[False].view(np.uint32))
     assert compare_frames(outs[True], want["out"]) <= RGB_ATOL
     assert int((want["hit_index"] >= 0).sum()) > 800
+
+
+def test_light_tiles_with_large_coordinates_and_a_far_light():
+    """the light tiles' registration pad and distance cut used to be absolute (1e-3 / 1e-4); the fp32 shadow ray
+    misses the exact line through the light by ~1e-7 x (coordinates + light distance), so a cloud 8 000 units from the origin
+    lit from 20 000 units away needs pads that scale. Default path == brute force bit for bit over the whole frame."""
+    rng = np.random.default_rng(811)
+    centre = np.array([3000.0, -2000.0, -7000.0])
+    objs = []
+    H = __import__("helpers")
+    for k in range(900):
+        pos = centre + rng.uniform(-60, 60, 3)
+        sc = np.full(3, rng.uniform(2.0, 7.0))
+        mv, inv = H.instance(pos, H.rotation(rng.normal(size=3), rng.uniform(0, 6)), sc)
+        mat = R.Material(ambient=rng.uniform(0, 1, 3), diffuse=rng.uniform(0, 1, 3), specular=rng.uniform(0, 1, 3),
+                         absorption=float(rng.choice([1.0, 0.5])), reflection=0.0, shininess=float(rng.choice([1.0, 12.0])))
+        objs.append(R.make_object(R.BOX if k % 9 == 0 else R.SPHERE, mat, mv, inv))
+    objs = R.objects_array(objs)
+    props = R.LightProperties((.1, .1, .1), (.5, .5, .5), (.6, .6, .6))
+    last = centre + np.array([9000.0, 14000.0, 11000.0])
+    lights = R.lights_array([R.make_light(props, position=(*(centre + rng.uniform(-20, 20, 3)), 1.0)),
+                             R.make_light(props, position=(*last, 1.0))])
+    # rays from the origin towards the cloud: a 128 x 96 fan around the direction of its centre
+    d0 = centre / np.linalg.norm(centre)
+    up = np.array([0.0, 1.0, 0.0])
+    ex = np.cross(d0, up); ex /= np.linalg.norm(ex)
+    ey = np.cross(ex, d0)
+    rays = np.zeros(128 * 96, dtype=R.RAY_DTYPE)
+    jj, ii = np.meshgrid(np.arange(96), np.arange(128), indexing="ij")
+    dirs = d0[None, :] + ((ii.ravel() - 64) / 64 * 0.0085)[:, None] * ex[None, :] + ((jj.ravel() - 48) / 48 * 0.0065)[:, None] * ey[None, :]
+    rays["start"] = np.array([0, 0, 0, 1], dtype=np.float32)
+    rays["direction"][:, :3] = dirs.astype(np.float32)
+    outs = {}
+    for grid in (True, False):
+        with hip(objs, lights, rays, 2, grid=grid) as rt:
+            outs[grid] = rt.Render()
+            st = rt.count_rays()
+            assert st.wavefront == 1
+            outs[(grid, "hits")] = st.hit_pixels
+    assert outs[(True, "hits")] > 3000
+    assert np.array_equal(outs[True].view(np.uint32), outs[False].view(np.uint32))
+
+
+def test_one_round_batches_finish_with_clean_flags(monkeypatch):
+    """with RT_WF_BATCH=1 (how one would bisect a round problem) wf_finish used to be launched with the FIRST
+    round's flags still set, and treated every remaining pixel as a primary-ray pixel. A frame small enough to be handed to
+    wf_finish right after the first round, forced through the large-scene path: same bits as the default batching."""
+    objs, lights = random_scene(20, 6, 3, seed=77, directional_lights=1)
+    rays = camera.primary_rays(32, 32)  # 1 024 pixels <= the finish threshold
+    with hip(objs, lights, rays, 3, path="wavefront") as rt:
+        want = rt.Render()
+    monkeypatch.setenv("RT_WF_BATCH", "1")
+    with hip(objs, lights, rays, 3, path="wavefront") as rt:
+        got = rt.Render()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))

@@ -23,6 +23,6 @@ python3 tools/ab/share_time.py 16 > $F/share_rehearsal.json 2> /dev/null
 RT_WALK_STATS=1 python3 bench.py --no-cpu-baseline --no-extra --steps 1 --warmup 0 2> $F/walk_stats_raw.txt > /dev/null; grep walk $F/walk_stats_raw.txt > $F/walk_stats.txt; rm -f $F/walk_stats_raw.txt
 for w in cfg2 cfg3 cfg5base cfg5; do python3 bench.py --workload $w --no-cpu-baseline > $F/bench_$w.json 2> $F/bench_$w.err; echo "$w done"; done
 python3 bench.py --workload cfg4 --ray-buffer --no-cpu-baseline --no-extra > $F/bench_cfg4_raybuffer.json 2> /dev/null || true
-for n in 2 4; do RT_BENCH_BACKEND=gloo RT_BENCH_ONE_GPU=1 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29900+n)) bench.py --gpus $n --no-cpu-baseline --no-extra > $F/bench_gloo_one_gpu_n$n.json 2> $F/bench_gloo_n$n.err || true; done
+for n in 2 4; do RT_BENCH_ONE_GPU=1 python3 bench.py --gpus $n --no-cpu-baseline --no-extra > $F/bench_gloo_one_gpu_n$n.json 2> $F/bench_gloo_n$n.err || true; done   # (bench.py starts its own ranks)
 rm -rf gpurun_out/frame_cfg4 gpurun_out/frame_cfg3
 ls -la $F

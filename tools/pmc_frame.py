@@ -85,6 +85,7 @@ traffic_total = (2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]) * 1024.0
 print(json.dumps({
     "workload": f"{workload}: ONE frame (the last of `bench.py --workload {workload} --steps 2 --warmup 1`), every kernel of the frame",
     "lib_sha16": lib_sha16,
+    "flags": sorted(f.lstrip("-") for f in os.environ.get("RT_PMC_FLAGS", "").split()),
     "frame_span_ms": span_ms, "kernel_ms_sum": tot["ns"] / 1e6,
     "hbm_bytes_per_launch": traffic_total,
     "fetch_bytes_raw": tot["FETCH_SIZE"] * 1024.0, "write_bytes": tot["WRITE_SIZE"] * 1024.0,
