@@ -193,13 +193,14 @@ def measure_brute_force_window(device_index, edge):
     return res
 
 
-def measure_cfg3(device_index):
-    """BASELINE configs[2] (simpleScene 4096x4096 shade_and_reflect depth 3): the small-scene kernel, HBM-write bound."""
+def measure_cfg3(device_index, fast_phong=False):
+    """BASELINE configs[2] (simpleScene 4096x4096 shade_and_reflect depth 3): the small-scene kernel, HBM-write bound.
+    fast_phong: the same frame under RT_FLAG_FAST_PHONG (opt-in; colours within 1e-5 of the reference, rays bit-exact)."""
     import torch
     from opencl_raytracer_amd.hip_raytracer import HIPRaytracer
     desc, objs, lights, W, H, kernel, depth = load_workload("cfg3")
     z = float(camera.camera_z(H))
-    rt = HIPRaytracer(objs, lights, None, depth, kernel=kernel, camera=(W, H, z), device=device_index)
+    rt = HIPRaytracer(objs, lights, None, depth, kernel=kernel, camera=(W, H, z), device=device_index, fast_phong=fast_phong)
     out = torch.empty((W * H, 4), dtype=torch.float32, device=torch.device("cuda", device_index))
     st = rt.count_rays()
     for _ in range(3):
@@ -215,7 +216,7 @@ def measure_cfg3(device_index):
     ms_sum, n = rt.timing_summary()
     kernel_ms = ms_sum / max(n, 1)
     alg = 16 * W * H + 320 * len(objs) + 64 * len(lights)
-    prof, why = frame_profile("cfg3")
+    prof, why = frame_profile("cfg3", ["--fast-phong"] if fast_phong else [])
     traffic = prof["hbm_bytes_per_launch"] if prof else None
     roof = {"bound": "hbm", "achieved": alg / (kernel_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": alg / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "kernel": "rt::render_pixels<2,true,false>",
@@ -289,6 +290,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary large-scene measurement")
     ap.add_argument("--literal", action="store_true", help="trace every ray the reference traces (no exact eliminations)")
     ap.add_argument("--ray-buffer", action="store_true", help="read primary rays from an uploaded buffer instead of in-kernel generation")
+    ap.add_argument("--fast-phong", action="store_true", help="RT_FLAG_FAST_PHONG: colour-only normalisations / specular power on the fast hardware paths (opt-in)")
     ap.add_argument("--no-grid", action="store_true", help="large scenes: test every object for every ray (brute-force traversal, the VALU-roofline kernel)")
     args = ap.parse_args()
 
@@ -347,18 +349,18 @@ def main():
     if crop is not None:
         rays = camera.crop_rays(W, H, *crop)
         rt = ShardedHIPRaytracer(objs, lights, rays, depth, kernel=kernel, tile_rows=args.tile_rows, width=crop[2],
-                                 device_index=local_rank, pipeline=pipeline, literal=args.literal, grid=not args.no_grid)
+                                 device_index=local_rank, pipeline=pipeline, literal=args.literal, grid=not args.no_grid, fast_phong=args.fast_phong)
         frame_w, frame_h = crop[2], crop[3]
         ray_source = "buffer"
     elif args.ray_buffer:
         rays = camera.primary_rays(W, H)
         rt = ShardedHIPRaytracer(objs, lights, rays, depth, kernel=kernel, tile_rows=args.tile_rows, width=W,
-                                 device_index=local_rank, pipeline=pipeline, literal=args.literal, raygen=False, grid=not args.no_grid)
+                                 device_index=local_rank, pipeline=pipeline, literal=args.literal, raygen=False, grid=not args.no_grid, fast_phong=args.fast_phong)
         frame_w, frame_h = W, H
         ray_source = "buffer"
     else:
         rt = ShardedHIPRaytracer(objs, lights, None, depth, camera=(W, H, z), kernel=kernel, tile_rows=args.tile_rows,
-                                 device_index=local_rank, pipeline=pipeline, literal=args.literal, grid=not args.no_grid)
+                                 device_index=local_rank, pipeline=pipeline, literal=args.literal, grid=not args.no_grid, fast_phong=args.fast_phong)
         frame_w, frame_h = W, H
         ray_source = "in-kernel pinhole"
     n_rays = rt.n_rays
@@ -414,6 +416,10 @@ def main():
     extra = {}
     if world == 1 and args.workload == "cfg4" and not args.no_extra:
         extra["cfg3"] = measure_cfg3(local_rank)
+        extra["cfg3_fast_phong"] = measure_cfg3(local_rank, fast_phong=True)
+        extra["cfg3_fast_phong"]["flag"] = ("RT_FLAG_FAST_PHONG (opt-in): shading normal / view vector / reflected light vector by v_rsq + "
+                                            "one Newton step, specular power by exp2(e log2 x); every ray bit-exact, colours within 1e-5 of the reference "
+                                            "(tests/test_fast_phong_gpu.py)")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
@@ -440,7 +446,7 @@ def main():
         local = rt.rt.local_rays
         alg_bytes = 16 * local + (32 * local if ray_source == "buffer" else 0) + 320 * len(objs) + 64 * len(lights)
         achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        run_flags = [f for f, on in (("--ray-buffer", args.ray_buffer), ("--literal", args.literal), ("--no-grid", args.no_grid)) if on]
+        run_flags = [f for f, on in (("--ray-buffer", args.ray_buffer), ("--literal", args.literal), ("--no-grid", args.no_grid), ("--fast-phong", args.fast_phong)) if on]
         prof, prof_why = (frame_profile(args.workload, run_flags) if world == 1 else (None, "counters are collected on one GPU"))
         traffic = prof["hbm_bytes_per_launch"] if prof else None
         out = {
@@ -454,7 +460,7 @@ def main():
                                      + (", frame k's exchange overlapped with frame k+1's render (self-checked against the synchronous exchange)" if pipeline else "")
                                      + (f" [{pipeline_note}]" if pipeline_note else ""))
                        if world > 1 else "single GPU", "arithmetic": "fused (fma where the OpenCL front-end marks fmuladd)",
-                       "literal": bool(args.literal)},
+                       "literal": bool(args.literal), "fast_phong": bool(args.fast_phong)},
             # `value` counts the rays the REFERENCE semantics trace for the frame (R_ref); what this backend
             # actually traced after its exact eliminations is rays_traced / mrays_traced_per_s - quote that one against
             # other raytracers

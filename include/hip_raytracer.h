@@ -80,6 +80,13 @@ typedef enum rt_kernel {
 #define RT_FLAG_MONOLITHIC 0x10u /* force the small-scene path (one fused kernel per frame); default: chosen by
                                     object count. Both paths produce identical bits.                          */
 
+#define RT_FLAG_FAST_PHONG 0x40u /* opt-in: values that feed COLOUR only (the shading normal, the view vector, the reflected
+                                    light vector, the specular power) on the hardware's fast reciprocal-square-root / log2 /
+                                    exp2 paths instead of IEEE sqrt + divisions and the library powf. Every ray - hit index, t,
+                                    shadow and reflection rays, the reference-equivalent ray count - stays bit-exact; colours
+                                    stay within the 1e-5 the reference comparison allows (north_star), not bit-identical to
+                                    the default arithmetic.                                                              */
+
 typedef struct rt_stats_t {
     uint64_t rays_traced;     /* rays this backend actually issued in the last counted render (R_act)          */
     uint64_t rays_reference;  /* rays the reference semantics trace for the same frame (R_ref)                 */

@@ -498,6 +498,7 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     p.scene.n_objs = c->n_objs;
     p.scene.n_lights = c->n_lights;
     p.scene.literal = (c->flags & RT_FLAG_LITERAL) ? 1u : 0u;
+    p.scene.fast_phong = (c->flags & RT_FLAG_FAST_PHONG) ? 1u : 0u;
     p.scene.nan_winner = c->nan_winner;
     p.scene.nan_winner_sphere = c->nan_winner_sphere ? 1u : 0u;
     p.rays = c->pinhole ? nullptr : c->d_rays;
@@ -1405,7 +1406,7 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
     if (kernel < 0 || kernel > 2) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "kernel must be 0, 1 or 2");
     if ((n_objs && !objs) || (n_lights && !lights))
         return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "objs/lights is NULL with a non-zero count");
-    if (flags & ~(RT_FLAG_UNFUSED | RT_FLAG_LITERAL | RT_FLAG_NO_RAYGEN | RT_FLAG_WAVEFRONT | RT_FLAG_MONOLITHIC | RT_FLAG_NO_GRID))
+    if (flags & ~(RT_FLAG_UNFUSED | RT_FLAG_LITERAL | RT_FLAG_NO_RAYGEN | RT_FLAG_WAVEFRONT | RT_FLAG_MONOLITHIC | RT_FLAG_NO_GRID | RT_FLAG_FAST_PHONG))
         return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "unknown flag bits");
     if (n_lights >= (1u << 22))  // the large-scene path keeps a pixel's light index in 22 bits of its phase word
         return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "more than 4 194 303 lights");

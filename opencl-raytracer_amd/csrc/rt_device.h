@@ -109,6 +109,22 @@ __device__ __forceinline__ void normalize3(float& x, float& y, float& z) {
     z = z / len;
 }
 
+// RT_FLAG_FAST_PHONG (opt-in): normalisation of a vector that feeds COLOUR only - the shading normal, the view vector, the
+// reflected light vector of the Phong term; never a vector a ray is built from. dot() as the reference's, then the
+// hardware reciprocal square root (1 ulp) with one Newton step and three multiplies instead of an IEEE square root and
+// three IEEE divisions (~8 instead of ~40 instructions); relative error ~1e-7, far inside the 1e-5 colour tolerance.
+__device__ __forceinline__ void normalize3_shading(bool fast, float& x, float& y, float& z) {
+    if (!fast) { normalize3(x, y, z); return; }
+    float s = x * x;
+    s = s + y * y;
+    s = s + z * z;
+    float r = __builtin_amdgcn_rsqf(s);
+    r = r * __builtin_fmaf(-0.5f * s, r * r, 1.5f);
+    x = x * r;
+    y = y * r;
+    z = z * r;
+}
+
 // one row of transform(): m0*x + m1*y + m2*z + m3*w in the reference's association
 template <bool FUSED>
 __device__ __forceinline__ float row4(float m0, float m1, float m2, float m3, float x, float y, float z, float w) {
@@ -606,6 +622,7 @@ struct Scene {
     uint32_t n_objs;
     uint32_t n_lights;
     uint32_t literal;  // RT_FLAG_LITERAL
+    uint32_t fast_phong;  // RT_FLAG_FAST_PHONG: colour-only normalisations and the specular power on the fast hardware paths
     int nan_winner;            // index of the LAST sphere / box of the scene (-1: none) and whether it is a sphere:
     uint32_t nan_winner_sphere;  // what the reference's loop ends with for a ray with a NaN in it (nan_ray_outcome)
 };
@@ -632,9 +649,13 @@ struct LightGeom {
 // pow(rDotV, fmax(shininess, 1)) (:232). An exponent of exactly 1 (the default material) returns the base:
 // that is what libm's powf returns for every finite x >= 0 (its error is orders of magnitude below half an ulp
 // there), and it saves the ~100-instruction OCML powf.
-__device__ __forceinline__ float specular_power(float rDotV, float shininess) {
+// RT_FLAG_FAST_PHONG: exp2(e log2 x) on the hardware's transcendental units (v_log_f32 / v_exp_f32, ~1 ulp each) instead of
+// OCML's ~100-instruction powf: relative error ~ e x 2^-23 ln 2 |log2 x| x ... - below 1e-5 of a colour channel for the
+// exponents a Phong material carries (measured over every golden vector and the shipped scenes: tests).
+__device__ __forceinline__ float specular_power(float rDotV, float shininess, bool fast = false) {
     const float e = __builtin_fmaxf(shininess, 1.f);
     if (e == 1.f) return rDotV;
+    if (fast) return rDotV > 0.f ? __builtin_amdgcn_exp2f(e * __builtin_amdgcn_logf(rDotV)) : 0.f;  // (rDotV = max(., 0): pow(0, e) = 0)
     return powf(rDotV, e);
 }
 
@@ -659,7 +680,7 @@ __device__ __forceinline__ void shadow_ray_to(const LightRec& L, float px, float
 // (shade_and_reflect_kernel.cl:194-224)
 template <bool FUSED>
 __device__ __forceinline__ void light_geometry(const LightRec& L, const HitRec& h, float nvx, float nvy, float nvz,
-                                               float vvx, float vvy, float vvz, LightGeom& g) {
+                                               float vvx, float vvy, float vvz, LightGeom& g, bool fast = false) {
     float nlx, nly, nlz;
     shadow_ray_to<FUSED>(L, h.px, h.py, h.pz, g.shadow, nlx, nly, nlz);
     g.nlx = nlx; g.nly = nly; g.nlz = nlz;
@@ -668,7 +689,7 @@ __device__ __forceinline__ void light_geometry(const LightRec& L, const HitRec& 
     float rx = fma_<FUSED>(kk, nvx, -nlx);
     float ry = fma_<FUSED>(kk, nvy, -nly);
     float rz = fma_<FUSED>(kk, nvz, -nlz);
-    normalize3(rx, ry, rz);
+    normalize3_shading(fast, rx, ry, rz);
     g.rDotV = __builtin_fmaxf(dot3(rx, ry, rz, vvx, vvy, vvz), 0.0f);
 }
 
@@ -698,16 +719,16 @@ __device__ __forceinline__ void shade_forward(const Scene& S, const HitRec& h, f
     const ColdObject* c = S.cold + h.index;
     const float4 amb = c->amb_absorb, dif = c->dif_shine, spec = c->spec_type;
     float nvx = h.nx, nvy = h.ny, nvz = h.nz;
-    normalize3(nvx, nvy, nvz);
+    normalize3_shading(S.fast_phong != 0u, nvx, nvy, nvz);
     float vvx = -h.px, vvy = -h.py, vvz = -h.pz;
-    normalize3(vvx, vvy, vvz);
+    normalize3_shading(S.fast_phong != 0u, vvx, vvy, vvz);
     cr = 0.f; cg = 0.f; cb = 0.f;
     float sr = 0.f, sg = 0.f, sb = 0.f;  // specular carried across iterations
     if constexpr (COUNT) ctr.reference += S.n_lights;
     for (uint32_t li = 0; li < S.n_lights; ++li) {
         const LightRec L = S.lights[li];
         LightGeom g;
-        light_geometry<FUSED>(L, h, nvx, nvy, nvz, vvx, vvy, vvz, g);
+        light_geometry<FUSED>(L, h, nvx, nvy, nvz, vvx, vvy, vvz, g, S.fast_phong != 0u);
         const bool lit = light_visible<FUSED, COUNT>(S, g.shadow, ctr);
         const float ar = amb.x * L.ambient.x, ag = amb.y * L.ambient.y, ab = amb.z * L.ambient.z;
         float dr, dg, db;
@@ -715,7 +736,7 @@ __device__ __forceinline__ void shade_forward(const Scene& S, const HitRec& h, f
             const float nd = __builtin_fmaxf(g.nDotL, 0.f);
             dr = (dif.x * L.diffuse.x) * nd; dg = (dif.y * L.diffuse.y) * nd; db = (dif.z * L.diffuse.z) * nd;
             if (g.nDotL > 0) {
-                const float pw = specular_power(g.rDotV, dif.w);
+                const float pw = specular_power(g.rDotV, dif.w, S.fast_phong != 0u);
                 sr = (spec.x * L.specular.x) * pw; sg = (spec.y * L.specular.y) * pw; sb = (spec.z * L.specular.z) * pw;
             }
         } else {
@@ -742,9 +763,9 @@ __device__ __forceinline__ void shade_last_light_wins(const Scene& S, const HitR
     const ColdObject* c = S.cold + h.index;
     const float4 amb = c->amb_absorb, dif = c->dif_shine, spec = c->spec_type;
     float nvx = h.nx, nvy = h.ny, nvz = h.nz;
-    normalize3(nvx, nvy, nvz);
+    normalize3_shading(S.fast_phong != 0u, nvx, nvy, nvz);
     float vvx = -h.px, vvy = -h.py, vvz = -h.pz;
-    normalize3(vvx, vvy, vvz);
+    normalize3_shading(S.fast_phong != 0u, vvx, vvy, vvz);
     float sr = 0.f, sg = 0.f, sb = 0.f;
     float dr = 0.f, dg = 0.f, db = 0.f;
     float ar = 0.f, ag = 0.f, ab = 0.f;
@@ -752,7 +773,7 @@ __device__ __forceinline__ void shade_last_light_wins(const Scene& S, const HitR
     for (uint32_t li = S.n_lights; li-- > 0 && need_specular;) {
         const LightRec L = S.lights[li];
         LightGeom g;
-        light_geometry<FUSED>(L, h, nvx, nvy, nvz, vvx, vvy, vvz, g);
+        light_geometry<FUSED>(L, h, nvx, nvy, nvz, vvx, vvy, vvz, g, S.fast_phong != 0u);
         const bool lit = light_visible<FUSED, COUNT>(S, g.shadow, ctr);
         if (li == S.n_lights - 1) {
             ar = amb.x * L.ambient.x; ag = amb.y * L.ambient.y; ab = amb.z * L.ambient.z;
@@ -764,7 +785,7 @@ __device__ __forceinline__ void shade_last_light_wins(const Scene& S, const HitR
         if (!lit) {
             need_specular = false;  // zeroed here, nothing later re-assigns it
         } else if (g.nDotL > 0) {
-            const float pw = specular_power(g.rDotV, dif.w);
+            const float pw = specular_power(g.rDotV, dif.w, S.fast_phong != 0u);
             sr = (spec.x * L.specular.x) * pw; sg = (spec.y * L.specular.y) * pw; sb = (spec.z * L.specular.z) * pw;
             need_specular = false;
         }

@@ -24,7 +24,7 @@ LIB_PATH = Path(__file__).resolve().parent / "csrc" / "libhip_raytracer.so"
 
 KERNEL_HITTEST, KERNEL_SHADE, KERNEL_SHADE_AND_REFLECT = 0, 1, 2
 KERNELS = {"hittest": 0, "shade": 1, "shade_and_reflect": 2}
-FLAG_UNFUSED, FLAG_LITERAL, FLAG_NO_RAYGEN, FLAG_WAVEFRONT, FLAG_MONOLITHIC, FLAG_NO_GRID = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20
+FLAG_UNFUSED, FLAG_LITERAL, FLAG_NO_RAYGEN, FLAG_WAVEFRONT, FLAG_MONOLITHIC, FLAG_NO_GRID, FLAG_FAST_PHONG = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
 
 EXPORTS = [
     "rt_abi_version", "rt_create", "rt_set_camera", "rt_set_shard", "rt_local_rays", "rt_render",
@@ -138,7 +138,7 @@ class HIPRaytracer:
     def __init__(self, objects: np.ndarray, lights: np.ndarray, rays: np.ndarray | None, MAX_BOUNCES: int = 0, *,
                  kernel="shade_and_reflect", device: int = 0, fused: bool = True, literal: bool = False,
                  raygen: bool = True, camera: tuple[int, int, float] | None = None, path: str = "auto",
-                 grid: bool = True):
+                 grid: bool = True, fast_phong: bool = False):
         self._lib = load_library()
         self._ctx = ctypes.c_void_p()
         objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
@@ -147,6 +147,7 @@ class HIPRaytracer:
         flags = (0 if fused else FLAG_UNFUSED) | (FLAG_LITERAL if literal else 0) | (0 if raygen else FLAG_NO_RAYGEN)
         flags |= {"auto": 0, "wavefront": FLAG_WAVEFRONT, "monolithic": FLAG_MONOLITHIC}[path]
         flags |= 0 if grid else FLAG_NO_GRID
+        flags |= FLAG_FAST_PHONG if fast_phong else 0
         if rays is not None:
             rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
             n_rays = int(rays.shape[0])
