@@ -1071,8 +1071,14 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
     const float wnx_f = (float)bg.wnx, wny_f = (float)bg.wny;
 
     unsigned long long s_rays = 0, s_trips = 0, s_live = 0, s_fetch = 0, s_pre = 0, s_flush = 0, s_refill = 0;  // STATS only
-    bool alive = false;   // the lane holds a ray ...
-    bool over = false;    // ... whose walk has ended (it may still wait for its parked exact test)
+    // The lane's state bits live in ONE vector register and are changed with vector and / or: as `bool`s carried round
+    // the loop the compiler keeps them as 64-bit lane masks in scalar registers, and every merge of divergent paths costs
+    // an andn2 / and / or triple per flag (round 2's walk: 0.75 scalar instructions per vector instruction).
+    constexpr uint32_t kAlive = 1u;    // the lane holds a ray ...
+    constexpr uint32_t kOver = 2u;     // ... whose walk has ended (it may still wait for its parked exact test)
+    constexpr uint32_t kPend = 4u;     // a candidate is parked for the next round of exact tests (pend_k)
+    constexpr uint32_t kSphere = 8u;   // the current best hit is a sphere (closest_take's tie rule)
+    uint32_t fl = 0u;
     uint32_t pix = 0;
     float rsx = 0.f, rsy = 0.f, rsz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, dd = 0.f;
     uint32_t cur = 0;                         // block to look at next (bits 0-23) and the entry to resume it at (bits 24-26)
@@ -1080,17 +1086,15 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
     float tx = 0.f, ty = 0.f, tz = 0.f, dtx = 0.f, dty = 0.f, dtz = 0.f;
     float T = kMaxFloat, limit = 0.f, t_stop = 0.f, slack = 0.f;
     int idx = -1;
-    bool cur_sphere = false;
-    bool pend = false;
     uint32_t pend_k = 0, done_k = 0xffffffffu;
 
     for (;;) {
         // ---- hand out rays to idle lanes ----
-        const unsigned long long idle = __ballot(!alive);
+        const unsigned long long idle = __ballot((fl & kAlive) == 0u);
         if (next < seg_end && ((uint32_t)__popcll(idle) >= (uint32_t)RT_WALK2_REFILL_MIN || idle == ~0ull)) {
             const uint32_t mine = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             if (STATS && lane == 0u) ++s_refill;
-            if (!alive && mine < seg_end) {
+            if ((fl & kAlive) == 0u && mine < seg_end) {
                 if (STATS) ++s_rays;
                 const uint32_t entry = w.identity_queue ? mine : queue[mine];
                 pix = w.identity_queue ? mine : (entry & kQueuePixel);
@@ -1098,7 +1102,8 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
                 const uint32_t note = __float_as_uint(ray.dw);  // begin_shade_lit's note: the object a reflection ray leaves
                 ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
                 rsx = ray.sx; rsy = ray.sy; rsz = ray.sz; rdx = ray.dx; rdy = ray.dy; rdz = ray.dz;
-                T = kMaxFloat; idx = -1; cur_sphere = false; pend = false; over = false;
+                T = kMaxFloat; idx = -1;
+                bool cur_sphere = false;
                 done_k = (w.first_round == 0u) ? note : 0xffffffffu;
                 dd = rdx * rdx + rdy * rdy + rdz * rdz;
                 slack = dd > 0.f ? kWalkSlackCells * bg.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
@@ -1128,19 +1133,19 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
                     limit = __builtin_fminf(T + slack, t_stop);
                 }
                 if (!start) store_closest_result(w, pix, T, idx);  // no cell to look at, or everything tested already
-                else alive = true;
+                fl = start ? (kAlive | (cur_sphere ? kSphere : 0u)) : 0u;
             }
             next += (uint32_t)__popcll(idle);
             if (next >= seg_end && more) more = grab();  // on to another run, if any is left
         }
-        const unsigned long long live = __ballot(alive);
+        const unsigned long long live = __ballot((fl & kAlive) != 0u);
         if (live == 0ull) {
             if (next >= seg_end) break;
             continue;
         }
         // ---- one trip: the block under the cursor ----
-        const bool walking = alive && !over;
-        bool stall = false;
+        const bool walking = (fl & (kAlive | kOver)) == kAlive;
+        uint32_t stalled = 0u;
         if (STATS) { if (lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); } if (walking) { s_pre += kBlockEntries; if ((cur & 0xffffffu) < bg.n_cells) ++s_fetch; } }
         if (walking) {
             const uint32_t b = cur & 0xffffffu, pos = cur >> 24;
@@ -1167,15 +1172,17 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
                 const uint32_t e = (uint32_t)__builtin_ctz(pm);
                 const uint32_t k = table_at(bg.ids, 8u * b + e);
                 // the same object again (parked, or tested a cell ago)? its result is known or on its way
-                const bool dup = (k == done_k) || (pend && k == pend_k);
-                if (!dup) {
-                    if (pend) { stall = true; back = e; break; }  // one parking slot: wait for the exact tests, resume here
-                    pend = true;
-                    pend_k = k;
-                }
-                pm &= pm - 1u;
+                const bool parked = (fl & kPend) != 0u;
+                const bool dup = (k == done_k) || (parked && k == pend_k);
+                const bool wait = !dup && parked;   // one parking slot: wait for the exact tests, resume at this entry
+                const bool take = !dup && !parked;
+                pend_k = take ? k : pend_k;
+                fl |= take ? kPend : 0u;
+                stalled = wait ? 1u : stalled;
+                back = wait ? e : back;
+                pm = wait ? 0u : (pm & (pm - 1u));
             }
-            const bool adv = !stall && nxt == 0u;  // the chain ends here: on to the next cell
+            const bool adv = stalled == 0u && nxt == 0u;  // the chain ends here: on to the next cell
             // the DDA step, computed by every lane, taken by those that advance (ties: x before y before z, as walk_next)
             const float tmin = __builtin_fminf(__builtin_fminf(tx, ty), tz);
             const bool ax = (tx <= ty) && (tx <= tz);
@@ -1187,37 +1194,38 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
             fx += (adv && ax) ? __builtin_copysignf(1.0f, rdx) : 0.f;
             fy += (adv && ay) ? __builtin_copysignf(1.0f, rdy) : 0.f;
             fz += (adv && az) ? __builtin_copysignf(1.0f, rdz) : 0.f;
-            over = adv && tmin > limit;
+            fl |= (adv && tmin > limit) ? kOver : 0u;
             const uint32_t cell = (uint32_t)__builtin_fmaf(__builtin_fmaf(fz, wny_f, fy), wnx_f, fx);  // (whole numbers below 2^24: exact)
-            cur = stall ? (b | (back << 24)) : (adv ? cell : nxt);
+            cur = stalled != 0u ? (b | (back << 24)) : (adv ? cell : nxt);
         }
         // ---- the exact tests, when enough lanes wait for them ----
-        const unsigned long long pending = __ballot(pend);
+        const unsigned long long pending = __ballot((fl & kPend) != 0u);
         if (pending != 0ull) {
-            const unsigned long long stuck = __ballot(pend && (stall || over));
+            const unsigned long long stuck = __ballot((fl & kPend) != 0u && (stalled != 0u || (fl & kOver) != 0u));
             const uint32_t n_live = (uint32_t)__popcll(live);
             if ((uint32_t)__popcll(pending) >= (uint32_t)RT_WALK2_DEFER_PENDING ||
                 ((uint32_t)__popcll(stuck) << RT_DEFER_STUCK_SHIFT) >= n_live) {
                 if (STATS && lane == 0u) ++s_flush;
-                if (pend) {
+                if ((fl & kPend) != 0u) {
                     float t;
                     bool sphere;
                     const Ray ray = {rsx, rsy, rsz, 1.0f, rdx, rdy, rdz, 0.0f};
                     const bool cand = lane_candidate<FUSED, true, false>(hot + pend_k, ray, t, sphere);
                     if (STATS) ++tested;
-                    pend = false;
                     done_k = pend_k;
+                    bool cur_sphere = (fl & kSphere) != 0u;
                     if (cand) {
                         closest_take(t, (int)pend_k, sphere, T, idx, cur_sphere);
                         limit = __builtin_fminf(T + slack, t_stop);
                     }
+                    fl = (fl & ~(kPend | kSphere)) | (cur_sphere ? kSphere : 0u);
                 }
             }
         }
         // ---- a finished walk with nothing parked: the ray is done ----
-        if (alive && over && !pend) {
+        if ((fl & (kAlive | kOver | kPend)) == (kAlive | kOver)) {
             store_closest_result(w, pix, T, idx);
-            alive = false;
+            fl = 0u;
         }
     }
     if (STATS) {
