@@ -1937,8 +1937,8 @@ static void launch_persistent(const WfParams& w, uint64_t n_max, uint32_t* ticke
     const bool tri = w.grid.has_triangles != 0u;
     // scenes without triangles: the unified walk (walk_segment), where its record table was built; RT_WALK2=closest / any /
     // none picks which of the two walks use it (measurement knob)
-    static const char* walk2_env = std::getenv("RT_WALK2");
-    static const char* walk3_env = std::getenv("RT_WALK3");  // "0": closest-hit rays through walk_segment / trace_segment instead
+    const char* walk2_env = std::getenv("RT_WALK2");  // (read per launch: tests switch walks inside one process)
+    const char* walk3_env = std::getenv("RT_WALK3");  // "0": closest-hit rays through walk_segment / trace_segment instead
     if (!ANY && !tri && w.bgrid.enabled && !(walk3_env && walk3_env[0] == '0')) {
         if (w.count_rays) hipLaunchKernelGGL((wf_walk_blocks<FUSED, true>), grid, block, 0, s, w, ticket);
         else hipLaunchKernelGGL((wf_walk_blocks<FUSED, false>), grid, block, 0, s, w, ticket);
