@@ -212,7 +212,7 @@ void repack_objects(const rt_object_data* objs, uint32_t n, std::vector<rt::HotP
             std::memcpy(&h.pad[0], &m[3], 4);
         }
         rt::ColdObject& c = cold[i];
-        std::memcpy(c.mv, o.mv, sizeof(c.mv));
+        for (int r = 0; r < 4; ++r) c.mv_row[r] = make_float4(o.mv[r], o.mv[4 + r], o.mv[8 + r], o.mv[12 + r]);
         c.inv_row3 = make_float4(m[3], m[7], m[11], m[15]);
         c.amb_absorb = make_float4(o.mat.ambient[0], o.mat.ambient[1], o.mat.ambient[2], o.mat.absorption);
         c.dif_shine = make_float4(o.mat.diffuse[0], o.mat.diffuse[1], o.mat.diffuse[2], o.mat.shininess);
@@ -499,6 +499,7 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     p.scene.n_lights = c->n_lights;
     p.scene.literal = (c->flags & RT_FLAG_LITERAL) ? 1u : 0u;
     p.scene.fast_phong = (c->flags & RT_FLAG_FAST_PHONG) ? 1u : 0u;
+    p.scene.affine = (c->affine_w && !c->has_triangles) ? 1u : 0u;
     p.scene.nan_winner = c->nan_winner;
     p.scene.nan_winner_sphere = c->nan_winner_sphere ? 1u : 0u;
     p.rays = c->pinhole ? nullptr : c->d_rays;

@@ -40,7 +40,9 @@ struct HotObject {   // 64 B, 64-B aligned: one s_load_dwordx16 per object per w
     // pad[0] = bits of R; (c, R) is the record's guard sphere
 };
 struct ColdObject {  // 128 B
-    float mv[16];        // column-major, as uploaded
+    float4 mv_row[4];    // mv by ROWS: row r = (m[r], m[4 + r], m[8 + r], m[12 + r]) of the column-major upload - one 16-byte
+                         // load per output component of `mv * p`, and the last row ((0,0,0,1) for an affine instance) is
+                         // only fetched for scenes that have a non-affine one (Scene::affine)
     float4 inv_row3;     // mvInverse row 3: (m[3], m[7], m[11], m[15])
     float4 amb_absorb;   // ambient rgb, absorption
     float4 dif_shine;    // diffuse rgb, shininess
@@ -521,12 +523,22 @@ __device__ __forceinline__ bool any_hit_small(const HotObject* __restrict__ hot_
 // ---- hit materialisation (once per finished ray) ---------------------------------------------------------
 // intersection = mv * p, normal = normalize((mv * (n,0)).xyz), reflection = reflect(dir, normal)
 // (shade_and_reflect_kernel.cl:112-118 sphere, :149-165 box, :175)
+// rows x,y,z of an object's mvInverse as materialise() loaded them (+ type and the triangle's guard radius): handed on to a
+// caller that is about to run the reference's exact test against the SAME object (the reflection ray's own object,
+// rt_wavefront.hip: begin_shade_lit), so that the 64-byte record is not gathered a second time
+struct ObjRows {
+    float4 r0, r1, r2;
+    uint32_t type, pad0;
+};
+
 template <bool FUSED>
 __device__ __forceinline__ void materialise(const HotObject* __restrict__ hot, const ColdObject* __restrict__ cold,
-                                            int index, float t, const Ray& ray, HitRec& h) {
+                                            int index, float t, const Ray& ray, HitRec& h, bool affine = false, ObjRows* rows = nullptr) {
     const HotObject* o = hot + index;
     const ColdObject* c = cold + index;
-    if (o->type == 2u) {  // triangle (extension): view-space point on the ray, normal = normalize(e1 x e2)
+    const uint32_t type = o->type;
+    if (rows) { rows->r0 = o->row0; rows->r1 = o->row1; rows->r2 = o->row2; rows->type = type; rows->pad0 = o->pad[0]; }
+    if (type == 2u) {  // triangle (extension): view-space point on the ray, normal = normalize(e1 x e2)
         const float4 e1 = o->row1, e2 = o->row2;
         h.px = fma_<FUSED>(t, ray.dx, ray.sx);
         h.py = fma_<FUSED>(t, ray.dy, ray.sy);
@@ -544,21 +556,31 @@ __device__ __forceinline__ void materialise(const HotObject* __restrict__ hot, c
         h.index = index;
         return;
     }
-    const float4 r0 = o->row0, r1 = o->row1, r2 = o->row2, r3 = c->inv_row3;
+    const float4 r0 = o->row0, r1 = o->row1, r2 = o->row2;
     const float sx = row4<FUSED>(r0.x, r0.y, r0.z, r0.w, ray.sx, ray.sy, ray.sz, ray.sw);
     const float sy = row4<FUSED>(r1.x, r1.y, r1.z, r1.w, ray.sx, ray.sy, ray.sz, ray.sw);
     const float sz = row4<FUSED>(r2.x, r2.y, r2.z, r2.w, ray.sx, ray.sy, ray.sz, ray.sw);
-    const float sw = row4<FUSED>(r3.x, r3.y, r3.z, r3.w, ray.sx, ray.sy, ray.sz, ray.sw);
     const float dx = row4<FUSED>(r0.x, r0.y, r0.z, r0.w, ray.dx, ray.dy, ray.dz, ray.dw);
     const float dy = row4<FUSED>(r1.x, r1.y, r1.z, r1.w, ray.dx, ray.dy, ray.dz, ray.dw);
     const float dz = row4<FUSED>(r2.x, r2.y, r2.z, r2.w, ray.dx, ray.dy, ray.dz, ray.dw);
-    const float dw = row4<FUSED>(r3.x, r3.y, r3.z, r3.w, ray.dx, ray.dy, ray.dz, ray.dw);
+    // Row w of the transforms. With bottom rows (0,0,0,1) - every instance of an `affine` scene, checked at upload - the
+    // reference's own expression 0*y + 0*x + 0*z + 1*w returns w for finite x, y, z (the zeros can only change the sign of a
+    // zero): the two 16-byte rows are not fetched and the identity is used instead.
+    float sw, dw;
+    if (affine) {
+        sw = ray.sw;
+        dw = ray.dw;
+    } else {
+        const float4 r3 = c->inv_row3;
+        sw = row4<FUSED>(r3.x, r3.y, r3.z, r3.w, ray.sx, ray.sy, ray.sz, ray.sw);
+        dw = row4<FUSED>(r3.x, r3.y, r3.z, r3.w, ray.dx, ray.dy, ray.dz, ray.dw);
+    }
     const float px = fma_<FUSED>(t, dx, sx);
     const float py = fma_<FUSED>(t, dy, sy);
     const float pz = fma_<FUSED>(t, dz, sz);
     const float pw = fma_<FUSED>(t, dw, sw);
     float ox, oy, oz;  // object-space normal
-    if (o->type == 0u) {
+    if (type == 0u) {
         ox = px; oy = py; oz = pz;
     } else {
         ox = 0.f; oy = 0.f; oz = 0.f;
@@ -566,14 +588,19 @@ __device__ __forceinline__ void materialise(const HotObject* __restrict__ hot, c
         if (py > 0.4998f) oy += 1.f; else if (py < -0.4998f) oy -= 1.f;
         if (pz > 0.4998f) oz += 1.f; else if (pz < -0.4998f) oz -= 1.f;
     }
-    const float* m = c->mv;
-    h.px = row4<FUSED>(m[0], m[4], m[8], m[12], px, py, pz, pw);
-    h.py = row4<FUSED>(m[1], m[5], m[9], m[13], px, py, pz, pw);
-    h.pz = row4<FUSED>(m[2], m[6], m[10], m[14], px, py, pz, pw);
-    h.pw = row4<FUSED>(m[3], m[7], m[11], m[15], px, py, pz, pw);
-    float nx = row4<FUSED>(m[0], m[4], m[8], m[12], ox, oy, oz, 0.f);
-    float ny = row4<FUSED>(m[1], m[5], m[9], m[13], ox, oy, oz, 0.f);
-    float nz = row4<FUSED>(m[2], m[6], m[10], m[14], ox, oy, oz, 0.f);
+    const float4 m0 = c->mv_row[0], m1 = c->mv_row[1], m2 = c->mv_row[2];
+    h.px = row4<FUSED>(m0.x, m0.y, m0.z, m0.w, px, py, pz, pw);
+    h.py = row4<FUSED>(m1.x, m1.y, m1.z, m1.w, px, py, pz, pw);
+    h.pz = row4<FUSED>(m2.x, m2.y, m2.z, m2.w, px, py, pz, pw);
+    if (affine) {
+        h.pw = pw;
+    } else {
+        const float4 m3 = c->mv_row[3];
+        h.pw = row4<FUSED>(m3.x, m3.y, m3.z, m3.w, px, py, pz, pw);
+    }
+    float nx = row4<FUSED>(m0.x, m0.y, m0.z, m0.w, ox, oy, oz, 0.f);
+    float ny = row4<FUSED>(m1.x, m1.y, m1.z, m1.w, ox, oy, oz, 0.f);
+    float nz = row4<FUSED>(m2.x, m2.y, m2.z, m2.w, ox, oy, oz, 0.f);
     normalize3(nx, ny, nz);
     h.nx = nx; h.ny = ny; h.nz = nz;
     const float k2 = dot3(ray.dx, ray.dy, ray.dz, nx, ny, nz) * -2.0f;
@@ -622,6 +649,7 @@ struct Scene {
     uint32_t n_objs;
     uint32_t n_lights;
     uint32_t literal;  // RT_FLAG_LITERAL
+    uint32_t affine;   // every mv / mvInverse has bottom row (0,0,0,1) exactly: materialise() skips the two rows it then knows
     uint32_t fast_phong;  // RT_FLAG_FAST_PHONG: colour-only normalisations and the specular power on the fast hardware paths
     int nan_winner;            // index of the LAST sphere / box of the scene (-1: none) and whether it is a sphere:
     uint32_t nan_winner_sphere;  // what the reference's loop ends with for a ray with a NaN in it (nan_ray_outcome)
@@ -842,7 +870,7 @@ __device__ __forceinline__ void shade_and_reflect_pixel(const Scene& S, uint32_t
         if (T == kMaxFloat) break;  // raycast() returned false (:173)
         if (!absorbing) break;
         HitRec rh;
-        materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
+        materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh, S.affine != 0u);
         shade_assign<FUSED, COUNT>(S, rh, rr, rg, rb, ctr);
         const float ra = (1.f - ap) * S.cold[rh.index].amb_absorb.w;
         abr = fma_<FUSED>(ra, rr, abr); abg = fma_<FUSED>(ra, rg, abg); abb = fma_<FUSED>(ra, rb, abb);

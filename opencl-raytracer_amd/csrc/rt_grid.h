@@ -266,6 +266,31 @@ __device__ __forceinline__ bool lane_candidate(const HotObject* __restrict__ o, 
     return false;
 }
 
+// ... of an object whose record is in registers already (materialise: ObjRows)
+template <bool FUSED, bool DW0>
+__device__ __forceinline__ bool rows_candidate(const ObjRows& o, const Ray& ray, float& t, bool& sphere) {
+    sphere = (o.type == 0u);
+    if (o.type == 2u)
+        return triangle_candidate(o.r0.x, o.r0.y, o.r0.z, o.r1.x, o.r1.y, o.r1.z, o.r2.x, o.r2.y, o.r2.z, o.r0.w, o.r1.w, o.r2.w,
+                                  __uint_as_float(o.pad0), ray, t);
+    const float sx = row4<FUSED>(o.r0.x, o.r0.y, o.r0.z, o.r0.w, ray.sx, ray.sy, ray.sz, ray.sw);
+    const float sy = row4<FUSED>(o.r1.x, o.r1.y, o.r1.z, o.r1.w, ray.sx, ray.sy, ray.sz, ray.sw);
+    const float sz = row4<FUSED>(o.r2.x, o.r2.y, o.r2.z, o.r2.w, ray.sx, ray.sy, ray.sz, ray.sw);
+    float dx, dy, dz;
+    if constexpr (DW0) {
+        dx = row3<FUSED>(o.r0.x, o.r0.y, o.r0.z, ray.dx, ray.dy, ray.dz);
+        dy = row3<FUSED>(o.r1.x, o.r1.y, o.r1.z, ray.dx, ray.dy, ray.dz);
+        dz = row3<FUSED>(o.r2.x, o.r2.y, o.r2.z, ray.dx, ray.dy, ray.dz);
+    } else {
+        dx = row4<FUSED>(o.r0.x, o.r0.y, o.r0.z, o.r0.w, ray.dx, ray.dy, ray.dz, ray.dw);
+        dy = row4<FUSED>(o.r1.x, o.r1.y, o.r1.z, o.r1.w, ray.dx, ray.dy, ray.dz, ray.dw);
+        dz = row4<FUSED>(o.r2.x, o.r2.y, o.r2.z, o.r2.w, ray.dx, ray.dy, ray.dz, ray.dw);
+    }
+    if (o.type == 0u) return sphere_candidate<FUSED>(sx, sy, sz, dx, dy, dz, t);
+    if (o.type == 1u) return box_candidate(sx, sy, sz, dx, dy, dz, t);
+    return false;
+}
+
 // A ray with a NaN in it walks no cells; what the reference's loop ends with for it is nan_ray_outcome() (rt_device.h),
 // patched in where the walk's result is produced (shadow rays) or consumed (closest_result, rt_wavefront.hip).
 __device__ __forceinline__ bool nan_shadow_blocked(const Scene& S, const Ray& ray) {

@@ -1361,19 +1361,20 @@ __device__ __forceinline__ void write_pixel(Ctx& c, float r, float g, float b) {
 template <bool FUSED>
 __device__ __forceinline__ void emit_shadow(Ctx& c, const HitRec& h, uint32_t li, uint32_t phase, bool new_hit) {
     const Scene& S = c.w.rp.scene;
-    float nvx = h.nx, nvy = h.ny, nvz = h.nz;
-    normalize3(nvx, nvy, nvz);
-    float vvx = -h.px, vvy = -h.py, vvz = -h.pz;
-    normalize3(vvx, vvy, vvz);
-    LightGeom g;
-    light_geometry<FUSED>(S.lights[li], h, nvx, nvy, nvz, vvx, vvy, vvz, g);
     // Through the grid the shadow ray is not stored: the trace kernels rebuild it from the hit point (shadow_of_pixel) - 32 bytes
-    // per shadow ray that wf_resume does not write and 16 that the walk does not read. The brute-force / literal trace kernels
-    // read the stored record; direction.w (0 for a shadow ray, read by no any-hit test) carries the light index there.
+    // per shadow ray that wf_resume does not write and 16 that the walk does not read - and nothing of the light's geometry is
+    // needed here. The brute-force / literal trace kernels read the stored record; direction.w (0 for a shadow ray, read by no
+    // any-hit test) carries the light index there.
     // (Not for meshes: their shadow walk is the heavier kernel, and the rebuild cost cfg5 58.5 -> 59.8 ms; cfg4: 16.74 -> 16.38.)
     if (shadow_rays_rebuilt(c.w)) {
         c.any_flag = (c.w.ltiles.enabled && li == c.w.ltiles.light) ? kQueueLastLight : 0u;
     } else {
+        float nvx = h.nx, nvy = h.ny, nvz = h.nz;
+        normalize3(nvx, nvy, nvz);
+        float vvx = -h.px, vvy = -h.py, vvz = -h.pz;
+        normalize3(vvx, vvy, vvz);
+        LightGeom g;
+        light_geometry<FUSED>(S.lights[li], h, nvx, nvy, nvz, vvx, vvy, vvz, g);
         g.shadow.dw = __uint_as_float(li);
         store_ray(c.w, c.i, g.shadow, kSlotShadow);
     }
@@ -1491,7 +1492,7 @@ __device__ __forceinline__ bool shade_last_light_inline(Ctx& c, const HitRec& h,
 // D + 2 big rounds instead of 2D + 2, every round traces shadow and reflection rays side by side, and wf_resume
 // touches the pixel state half as often. `spec_bounces` / `spec_ap`: the loop state as it will be after this hit.
 template <int KERNEL, bool FUSED>
-__device__ __forceinline__ void begin_shade_lit(Ctx& c, const HitRec& h, bool primary, uint32_t spec_bounces, float spec_ap) {
+__device__ __forceinline__ void begin_shade_lit(Ctx& c, const HitRec& h, bool primary, uint32_t spec_bounces, float spec_ap, const ObjRows& rows) {
     const Scene& S = c.w.rp.scene;
     c.reference += S.n_lights;
     uint32_t flag = 0u;
@@ -1513,7 +1514,7 @@ __device__ __forceinline__ void begin_shade_lit(Ctx& c, const HitRec& h, bool pr
             // slot) that this object is done. If the test ever reports a hit, nothing is said and the walk tests it as usual.
             float t_self;
             bool sphere_self;
-            const bool self_hit = lane_candidate<FUSED, true, true>(S.hot + h.index, ray, t_self, sphere_self);
+            const bool self_hit = rows_candidate<FUSED, true>(rows, ray, t_self, sphere_self);  // (the record materialise() just read)
             ray.dw = __uint_as_float(self_hit ? 0xffffffffu : (uint32_t)h.index);
         }
         store_ray(c.w, c.i, ray, kSlotClosest);
@@ -1529,9 +1530,9 @@ __device__ __forceinline__ void begin_shade_lit(Ctx& c, const HitRec& h, bool pr
 
 // ... or, without lights, go straight on (shade() returns black)
 template <int KERNEL, bool FUSED>
-__device__ __forceinline__ void begin_shade(Ctx& c, const HitRec& h, bool primary, uint32_t spec_bounces, float spec_ap) {
+__device__ __forceinline__ void begin_shade(Ctx& c, const HitRec& h, bool primary, uint32_t spec_bounces, float spec_ap, const ObjRows& rows) {
     if (c.w.rp.scene.n_lights == 0) { shade_done<KERNEL, FUSED>(c, h, primary, 0.f, 0.f, 0.f); return; }  // (h travels in registers)
-    begin_shade_lit<KERNEL, FUSED>(c, h, primary, spec_bounces, spec_ap);
+    begin_shade_lit<KERNEL, FUSED>(c, h, primary, spec_bounces, spec_ap, rows);
 }
 
 // one light-loop iteration, resumed with the visibility of light `li`; mirrors shade_forward /
@@ -1676,14 +1677,15 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
         if (!c.pre) ray = load_ray(c.w, i, kSlotClosest);
         ray.dw = 0.0f;  // (a reflection ray's direction.w; the slot may carry begin_shade_lit's note to the walk)
         HitRec rh;
-        materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
+        ObjRows rows;
+        materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh, S.affine != 0u, &rows);
         store_loop_state(c, abr, abg, abb, rr, rg, rb, ap, bounces, false);
         if (c.pre) {  // the step may go on to shade rh on the spot (shade_last_light_inline): what it preloaded is now this
             c.pre_acc = make_float4(abr, abg, abb, ap);
             c.pre_res.w = __uint_as_float(bounces);
         }
         const float ra = (1.f - ap) * S.cold[rh.index].amb_absorb.w;  // shade_done's update, ahead of time
-        begin_shade_lit<2, FUSED>(c, rh, false, bounces, ap + ra);
+        begin_shade_lit<2, FUSED>(c, rh, false, bounces, ap + ra, rows);
         return;
     }
     Ray ray;
@@ -1744,8 +1746,9 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
         } else {
             const Ray ray = closest_ray(w, i, true);
             HitRec h;
-            materialise<FUSED>(S.hot, S.cold, idx, T, ray, h);
-            begin_shade<KERNEL, FUSED>(c, h, true, w.rp.max_bounces, S.cold[h.index].amb_absorb.w);
+            ObjRows rows;
+            materialise<FUSED>(S.hot, S.cold, idx, T, ray, h, S.affine != 0u, &rows);
+            begin_shade<KERNEL, FUSED>(c, h, true, w.rp.max_bounces, S.cold[h.index].amb_absorb.w, rows);
         }
     } else if (phase == PH_SHADOW_PRIMARY || phase == PH_SHADOW_REFLECT) {
         c.pre = true;
@@ -1769,8 +1772,9 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
             Ray ray = load_ray(w, i, kSlotClosest);
             ray.dw = 0.0f;  // (a reflection ray's direction.w; the slot may carry begin_shade_lit's note to the walk)
             HitRec rh;
-            materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh);
-            begin_shade<KERNEL, FUSED>(c, rh, false, bounces, ap + (1.f - ap) * S.cold[rh.index].amb_absorb.w);
+            ObjRows rows;
+            materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh, S.affine != 0u, &rows);
+            begin_shade<KERNEL, FUSED>(c, rh, false, bounces, ap + (1.f - ap) * S.cold[rh.index].amb_absorb.w, rows);
         }
     }
 }
