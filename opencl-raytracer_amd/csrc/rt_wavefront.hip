@@ -1936,8 +1936,16 @@ static void launch_persistent(const WfParams& w, uint64_t n_max, uint32_t* ticke
     // The shadow walk (light tiles: two or three short trips per ray) is bound by what a wave costs to start, not by how many
     // rays are in flight: MEASURED, rank 0's share of the cfg4 frame at world = 1 / 2 / 4 / 8 with its wave cap at 8192:
     // 17.44 / 9.51 / 5.57 / 3.59 ms; 4096: 17.40 / 9.34 / 5.31 / 3.39; 2048: 18.15 / 9.57 / 5.36 / 3.32; 1024: 20.2 / 10.6 / 5.9 / 3.56.
-    const uint64_t any_cap = std::min<uint64_t>(RT_MAX_WAVES_ANY_SHARED, n_max <= (3ull << 20) ? 2048u : 4096u);
-    const dim3 grid = persistent_grid(n_max, ANY ? any_cap : (shared ? RT_MAX_WAVES_CLOSEST_SHARED : RT_MAX_WAVES)), block(256);
+    uint64_t any_cap = std::min<uint64_t>(RT_MAX_WAVES_ANY_SHARED, n_max <= (3ull << 20) ? 2048u : 4096u);
+    // Round 3, block walk: a SMALL closest-hit queue (one rank's share of the frame at 8 ranks: 2.1 M pixels) is better served by
+    // 4 waves per SIMD than by all 6 - the queue holds only ~3 rays per lane slot, the launch is mostly its own tail, and the
+    // shadow walk finds free slots beside it instead of running in that tail. MEASURED, rank 0's share at world = 1 / 2 / 4 / 8,
+    // closest / shadow wave caps: 8192 / 4096|2048: 12.66 / 6.84 / 3.94 / 2.55 ms; 4096 / 2048 everywhere: 12.97 / 6.98 / 3.98 / 2.32;
+    // 5120 / 1024: 13.49 / 7.10 / 3.96 / 2.39.
+    uint64_t closest_cap = shared ? (n_max <= (3ull << 20) ? std::min<uint64_t>(RT_MAX_WAVES_CLOSEST_SHARED, 4096u) : RT_MAX_WAVES_CLOSEST_SHARED) : RT_MAX_WAVES;
+    if (const char* env = std::getenv("RT_WAVES_CLOSEST")) closest_cap = (uint64_t)std::max(64, std::atoi(env));  // measurement knobs
+    if (const char* env = std::getenv("RT_WAVES_ANY")) any_cap = (uint64_t)std::max(64, std::atoi(env));
+    const dim3 grid = persistent_grid(n_max, ANY ? any_cap : closest_cap), block(256);
     const bool tri = w.grid.has_triangles != 0u;
     // scenes without triangles: the unified walk (walk_segment), where its record table was built; RT_WALK2=closest / any /
     // none picks which of the two walks use it (measurement knob)
