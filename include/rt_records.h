@@ -12,6 +12,10 @@
  *   rt_light       64 B   +0 ambient  +16 diffuse  +32 specular  +48 position (w=1 positional, w=0 directional)
  *   rt_ray         32 B   +0 start (w=1)  +16 direction (w=0, not normalised)
  *   rt_pixel       16 B   float3 colour in a float4 slot (cl_float3 == cl_float4)
+ *
+ * Alignment is the CALLER's business: the OpenCL types are 16- / 64-byte aligned (cl_float16 members), these plain C structs
+ * ask for 4. The ABI only ever copies the arrays byte for byte (rt_create: "host buffers are copied"), so any alignment works;
+ * a caller that casts a reference-side cl_ObjectData array to `const void*` passes exactly these bytes.
  */
 #ifndef RT_RECORDS_H
 #define RT_RECORDS_H
