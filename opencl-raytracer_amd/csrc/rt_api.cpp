@@ -771,6 +771,7 @@ int build_walk_blocks(rt_context* c, uint32_t n, const std::vector<Bound>& sph, 
     }
     const uint64_t n_cells = wn[0] * wn[1] * wn[2];
     if (n_cells >= (1ull << 24)) return RT_OK;  // block indices are 24 bits in a header
+    if (n_cells > 64ull * n + (1ull << 18)) return RT_OK;  // a few objects in a huge box: 64 bytes per (mostly empty) cell would be all table
     float c0[3];
     for (int a = 0; a < 3; ++a) c0[a] = (float)((double)lof[a] + (0.5 - B) * (double)cellf);
     const volatile float inv_step_v = 128.0f / cellf;
