@@ -109,7 +109,11 @@ struct BlockGrid {
     uint32_t enabled;
 };
 constexpr uint32_t kBlockBorder = 2;
-constexpr uint32_t kBlockEntries = 7;
+#ifndef RT_BLOCK_ENTRIES
+#define RT_BLOCK_ENTRIES 7   // candidates a block holds (<= 7); 4 / 5 / 6 with their best cell edge: 13.11 / 12.86 / 12.74 vs 12.67 ms per cfg4 frame
+#endif
+constexpr uint32_t kBlockEntries = RT_BLOCK_ENTRIES;
+static_assert(kBlockEntries >= 1 && kBlockEntries <= 7, "a block is a header word and up to seven 4-byte candidates");
 
 // Element `index` of a read-only table smaller than 4 GiB (build_grid / build_light_tiles refuse larger ones): the byte
 // offset is formed in 32 bits, so the load takes the scalar-base + 32-bit-vector-offset form instead of a 64-bit vector

@@ -1159,12 +1159,12 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
             const float olz = __builtin_fmaf(rsz - __builtin_fmaf(fz, bg.cell, bg.c0z), inv, 128.0f);
             uint32_t pm = 0u;  // candidates that pass the pre-test: bit e = entry e (fed last to first)
             const float neg_dd = -dd, oma = 1.0f - g.pretest_alpha;
-            pm = lattice_pretest(pm, q1.w, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
-            pm = lattice_pretest(pm, q1.z, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
-            pm = lattice_pretest(pm, q1.y, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
-            pm = lattice_pretest(pm, q1.x, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
-            pm = lattice_pretest(pm, q0.w, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
-            pm = lattice_pretest(pm, q0.z, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            if constexpr (kBlockEntries > 6) pm = lattice_pretest(pm, q1.w, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            if constexpr (kBlockEntries > 5) pm = lattice_pretest(pm, q1.z, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            if constexpr (kBlockEntries > 4) pm = lattice_pretest(pm, q1.y, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            if constexpr (kBlockEntries > 3) pm = lattice_pretest(pm, q1.x, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            if constexpr (kBlockEntries > 2) pm = lattice_pretest(pm, q0.w, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            if constexpr (kBlockEntries > 1) pm = lattice_pretest(pm, q0.z, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
             pm = lattice_pretest(pm, q0.y, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
             pm &= 0x7fu << pos;  // (a block the lane comes back to: the entries before `pos` have been dealt with)
             uint32_t back = 0u;
