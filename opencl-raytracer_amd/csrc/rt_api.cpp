@@ -86,6 +86,8 @@ struct rt_context {
     std::vector<float> h_grid_pre;          // per object: pre-test radius as the grid's entry spheres carry it
     uint2* d_lt_range = nullptr;            // light tiles (rt_grid.h: LightTiles) for the last light's shadow rays
     float4* d_lt_records = nullptr;
+    uint4* d_lt_blocks = nullptr;           // the light tiles' lists as blocks of three candidates (LightTiles::blocks)
+    uint32_t* d_lt_block_ids = nullptr;
     rt::LightTiles light_tiles = {};
     rt::BlockGrid blocks = {};              // the closest-hit walk's coarse grid of 32-byte blocks (rt_grid.h: BlockGrid)
     uint4* d_walk_blocks = nullptr;
@@ -1376,6 +1378,86 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
     lt.light = li;
     lt.cut_pad = (float)std::max(1e-4, 4e-7 * (2.0 * coord_max + reach_max));
     lt.enabled = 1u;
+    if (!c->has_triangles && total && !std::getenv("RT_NO_LT_BLOCKS")) {
+        // ... and as 32-byte blocks of three candidates (LightTiles::blocks). Lattice: 16 bits per axis over the grid box; every
+        // sphere rounded outwards exactly as build_walk_blocks does it (the device's own fma for the centre, the known
+        // quantisation error d added to the radius with the cross term of the distance-dependent tolerance:
+        // w'^2 = (w + d)^2 + 2 d sqrt(a) D + a (2 d D + d^2), a = the pre-test's alpha, D = the grid box's diagonal).
+        const rt::GridDesc& g = c->grid;
+        const float lof[3] = {g.lox, g.loy, g.loz};
+        const double ext = (double)g.cell * std::max(g.nx, std::max(g.ny, g.nz));
+        const volatile float stepv = (float)(ext / 65535.0 * (1.0 + 1e-6));
+        const float stepf = stepv;
+        const double Dbox = std::sqrt((double)g.cell * g.nx * (double)g.cell * g.nx + (double)g.cell * g.ny * (double)g.cell * g.ny +
+                                      (double)g.cell * g.nz * (double)g.cell * g.nz);
+        const double a0 = (double)g.pretest_alpha, sa0 = std::sqrt(a0);
+        std::vector<uint16_t> q(3 * (size_t)n, 0);
+        std::vector<double> wq(n, 0.0);
+        double rmax = 0.0, kmax = 0.0;
+        bool ok = stepf > 0.f && std::isfinite(stepf);
+        for (uint32_t i = 0; i < n && ok; ++i) {
+            if (!(rect[i].u1 >= rect[i].u0)) continue;
+            double d2 = 0;
+            for (int a = 0; a < 3; ++a) {
+                const double cc = c->h_grid_spheres[4 * i + a];
+                double u = std::floor((cc - (double)lof[a]) / (double)stepf + 0.5);
+                if (!(u >= 0.0) || !(u <= 65535.0)) { ok = false; break; }  // (a centre outside the grid box: cannot happen for registered objects)
+                q[3 * i + a] = (uint16_t)u;
+                const double dec = (double)std::fmaf((float)u, stepf, lof[a]);
+                d2 += (cc - dec) * (cc - dec);
+            }
+            const double w = std::fabs((double)c->h_grid_pre[i]), d = std::sqrt(d2);  // (the ray is not transformed here: no further term)
+            const double w2 = (w + d) * (w + d) + 2.0 * d * sa0 * Dbox + a0 * (2.0 * d * Dbox + d * d);
+            wq[i] = std::sqrt(w2) * (1.0 + 2e-6);
+            rmax = std::max(rmax, wq[i]);
+            kmax = std::max(kmax, (double)key[i]);
+        }
+        const volatile float rstepv = (float)(rmax / 255.0 * (1.0 + 1e-5)), kstepv = (float)(std::max(kmax, 1e-3) / 255.0 * (1.0 + 1e-5));
+        const float rstepf = rstepv, kstepf = kstepv;
+        ok = ok && rstepf > 0.f && std::isfinite(rstepf) && std::isfinite(kstepf) && (uint64_t)ranges.size() + total / 3 + ranges.size() < (1ull << 30);
+        if (ok) {
+            const size_t heads = ranges.size();
+            std::vector<uint32_t> blk(8 * heads, 0u), bid(4 * heads, c->n_objs);
+            const uint32_t empty_hi = 0xff000000u;
+            for (size_t b = 0; b < heads; ++b) blk[8 * b + 3] = blk[8 * b + 5] = blk[8 * b + 7] = empty_hi;
+            for (size_t t = 0; t < heads; ++t) {
+                size_t at = t;
+                for (uint32_t j = 0; j < ranges[t].y; ++j) {
+                    const uint32_t slot = j % 3u;
+                    if (j && slot == 0u) {  // the chain goes on in a new block behind the heads
+                        const size_t nb = blk.size() / 8;
+                        blk.resize(blk.size() + 8, 0u);
+                        bid.resize(bid.size() + 4, c->n_objs);
+                        blk[8 * nb + 3] = blk[8 * nb + 5] = blk[8 * nb + 7] = empty_hi;
+                        blk[8 * at] = (uint32_t)nb;
+                        at = nb;
+                    }
+                    const uint32_t i = entries[(size_t)ranges[t].x + j];
+                    uint32_t r8 = (uint32_t)std::ceil(wq[i] / (double)rstepf);
+                    while (r8 < 255u && (double)((float)r8 * rstepf) < wq[i]) ++r8;  // (the device's own product must not fall short)
+                    if (r8 > 255u) r8 = 255u;
+                    double kk = std::floor(std::max((double)key[i], 0.0) / (double)kstepf * (1.0 - 1e-6));
+                    uint32_t k8 = (uint32_t)std::min(255.0, std::max(0.0, kk));
+                    while (k8 > 0u && (double)((float)k8 * kstepf) > (double)key[i]) --k8;  // (rounded DOWN: an entry may only look nearer to the light)
+                    blk[8 * at + 2 + 2 * slot] = (uint32_t)q[3 * i] | ((uint32_t)q[3 * i + 1] << 16);
+                    blk[8 * at + 3 + 2 * slot] = (uint32_t)q[3 * i + 2] | (r8 << 16) | (k8 << 24);
+                    bid[4 * at + slot] = i;
+                }
+            }
+            RT_HIP(c, hipMalloc((void**)&c->d_lt_blocks, sizeof(uint32_t) * blk.size()));
+            RT_HIP(c, hipMalloc((void**)&c->d_lt_block_ids, sizeof(uint32_t) * bid.size()));
+            RT_HIP(c, hipMemcpy(c->d_lt_blocks, blk.data(), sizeof(uint32_t) * blk.size(), hipMemcpyHostToDevice));
+            RT_HIP(c, hipMemcpy(c->d_lt_block_ids, bid.data(), sizeof(uint32_t) * bid.size(), hipMemcpyHostToDevice));
+            lt.blocks = c->d_lt_blocks;
+            lt.block_ids = c->d_lt_block_ids;
+            lt.lat_lox = lof[0]; lt.lat_loy = lof[1]; lt.lat_loz = lof[2];
+            lt.lat_step = stepf; lt.rstep = rstepf; lt.kstep = kstepf;
+            lt.blocks_enabled = 1u;
+            if (std::getenv("RT_WALK_STATS"))
+                std::fprintf(stderr, "[light tiles] %u x %u tiles, %llu entries, %zu blocks (%zu behind the heads), lattice step %g, radius step %g, key step %g\n",
+                             T, T, (unsigned long long)total, blk.size() / 8, blk.size() / 8 - heads, (double)stepf, (double)rstepf, (double)kstepf);
+        }
+    }
     if (!c->h_walk.empty() && total) {  // the same lists as records of the unified walk, each tile's chained to its end
         const uint64_t base = c->h_walk.size() / 2;
         if ((base + total) * 32ull < 0xf0000000ull) {
@@ -1751,6 +1833,8 @@ void rt_destroy(rt_context* c) {
     if (c->d_tile_entries) (void)hipFree(c->d_tile_entries);
     if (c->d_lt_range) (void)hipFree(c->d_lt_range);
     if (c->d_lt_records) (void)hipFree(c->d_lt_records);
+    if (c->d_lt_blocks) (void)hipFree(c->d_lt_blocks);
+    if (c->d_lt_block_ids) (void)hipFree(c->d_lt_block_ids);
     if (c->d_walk_rec) (void)hipFree(c->d_walk_rec);
     if (c->d_walk_blocks) (void)hipFree(c->d_walk_blocks);
     if (c->d_walk_ids) (void)hipFree(c->d_walk_ids);

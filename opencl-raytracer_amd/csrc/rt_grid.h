@@ -156,6 +156,19 @@ struct LightTiles {
     uint32_t enabled;
     uint32_t walk_base;                        // entry e of a tile = record walk_base + e of GridDesc::walk_rec (0: not built)
     float cut_pad;                             // absolute slack of the distance cut: the rounding of origin - light (scales with the coordinates)
+    // The same lists as 32-byte BLOCKS of three candidates (scenes without triangles; round 3): a shadow ray looks at 2.4 entries of
+    // its tile on average, each a 32-byte record in a table of tens of MB - 2.4 line fills from beyond L2 per ray, which is what the
+    // shadow walk was paying for (rt_grid.h: BlockGrid has the cost model). Block t (t < tiles_u tiles_v) is the HEAD of tile t's
+    // chain and sits in a table small enough for L2 (2 MB at 256 x 256 tiles); further blocks follow behind the heads.
+    //   word 0   next block (0: the chain ends)        word 1   unused
+    //   words 2-7   three candidates, two words each: {x16 | y16 << 16, z16 | r8 << 16 | k8 << 24} - the centre on a 16-bit lattice
+    //               over the grid box (lat_lo + q lat_step), the pre-test radius r8 rstep rounded UP (quantisation error of the
+    //               centre included, build_light_tiles), the distance key k8 kstep rounded DOWN; an empty slot has k8 = 255, r8 = 0
+    // block_ids: 4 per block (slot 3 unused), read only for candidates that pass the pre-test.
+    const uint4* __restrict__ blocks;
+    const uint32_t* __restrict__ block_ids;
+    float lat_lox, lat_loy, lat_loz, lat_step, rstep, kstep;
+    uint32_t blocks_enabled;
 };
 
 // tile of the ray whose ORIGIN is `s` (any point of the line through the light does): false = no object in that direction

@@ -743,6 +743,14 @@ __device__ __forceinline__ bool misses_bounding_sphere2(const float4 s, float sx
     return disc < 0.f || (od < 0.f && c > 1.0e-5f * oo);
 }
 
+// one candidate of a light-tile block (LightTiles::blocks): decoded sphere and distance key
+__device__ __forceinline__ void lt_block_entry(const LightTiles& lt, uint32_t lo, uint32_t hi, float4& sphere, float& key) {
+    const float r = (float)((hi >> 16) & 0xffu) * lt.rstep;
+    sphere = make_float4(__builtin_fmaf((float)(lo & 0xffffu), lt.lat_step, lt.lat_lox), __builtin_fmaf((float)(lo >> 16), lt.lat_step, lt.lat_loy),
+                         __builtin_fmaf((float)(hi & 0xffffu), lt.lat_step, lt.lat_loz), r * r);
+    key = (float)(hi >> 24) * lt.kstep;
+}
+
 template <bool FUSED, bool ANY, bool STATS>
 __device__ __forceinline__ void walk_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue,
                                              uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr,
@@ -801,6 +809,7 @@ __device__ __forceinline__ void walk_segment(const WfParams& w, const uint32_t* 
     int idx = -1;
     bool cur_sphere = false;
     bool pend = false;
+    bool in_lt_blocks = false;  // shadow ray of the last light whose list is a chain of three-candidate blocks (LightTiles::blocks)
     uint32_t pend_k = 0, done_k = 0xffffffffu;
 
     for (;;) {
@@ -823,7 +832,7 @@ __device__ __forceinline__ void walk_segment(const WfParams& w, const uint32_t* 
                 }
                 ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
                 rsx = ray.sx; rsy = ray.sy; rsz = ray.sz; rdx = ray.dx; rdy = ray.dy; rdz = ray.dz;
-                T = kMaxFloat; idx = -1; cur_sphere = false; pend = false; over = false;
+                T = kMaxFloat; idx = -1; cur_sphere = false; pend = false; over = false; in_lt_blocks = false;
                 done_k = (!ANY && w.first_round == 0u) ? note : 0xffffffffu;
                 dd = rdx * rdx + rdy * rdy + rdz * rdz;
                 const float slk = dd > 0.f ? kWalkSlackCells * g.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
@@ -835,14 +844,24 @@ __device__ __forceinline__ void walk_segment(const WfParams& w, const uint32_t* 
                     float cut;
                     const float chk = ((rsx + rsy) + rsz) + ((rdx + rdy) + rdz);
                     if (chk == chk && light_tile_of(w.ltiles, rsx, rsy, rsz, tile, cut)) {
-                        const uint2 range = table_at(w.ltiles.tile_range, tile);
-                        if (range.y != 0u) {
+                        if (w.ltiles.blocks_enabled) {
+                            // the tile's chain of three-candidate blocks; its head is block `tile` (an empty tile's head holds nothing
+                            // nearer than "beyond": the first trip ends the walk)
                             start = true;
-                            cursor = w.ltiles.walk_base + range.x;
-                            slack = cut;        // how far from the light an occluder can start
-                            limit = -1.0f;      // the list is all there is: its end ends the walk (0 > -1)
-                            tx = ty = tz = 0.f; dtx = dty = dtz = 0.f;
-                            stx = sty = stz = 0; cell = 0u;
+                            cursor = tile;
+                            in_lt_blocks = true;
+                            slack = cut;
+                            limit = -1.0f;
+                        } else {
+                            const uint2 range = table_at(w.ltiles.tile_range, tile);
+                            if (range.y != 0u) {
+                                start = true;
+                                cursor = w.ltiles.walk_base + range.x;
+                                slack = cut;        // how far from the light an occluder can start
+                                limit = -1.0f;      // the list is all there is: its end ends the walk (0 > -1)
+                                tx = ty = tz = 0.f; dtx = dty = dtz = 0.f;
+                                stx = sty = stz = 0; cell = 0u;
+                            }
                         }
                     }
                 } else {
@@ -902,7 +921,43 @@ __device__ __forceinline__ void walk_segment(const WfParams& w, const uint32_t* 
         const bool walking = alive && !over;
         bool stall = false;
         if (STATS) { if (lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); } if (walking) { ++s_pre; if (cursor < g.walk_cells) ++s_fetch; } }
-        if (walking) {
+        if (ANY && walking && in_lt_blocks) {
+            // ---- a light tile's block: three candidates per 32-byte fetch (the shadow walk was paying for 2.4 record fetches per ray)
+            const LightTiles& lt = w.ltiles;
+            const uint32_t b = cursor & 0xffffffu, pos = cursor >> 24;
+            const uint4 q0 = table_at(lt.blocks, 2u * b), q1 = table_at(lt.blocks, 2u * b + 1u);
+            const uint32_t nxt = q0.x;
+            const uint32_t lo[3] = {q0.z, q1.x, q1.z}, hi[3] = {q0.w, q1.y, q1.w};
+            uint32_t pm = 0u;
+            bool beyond = false;  // sorted by distance from the light: an entry beyond the ray's origin ends the list
+#pragma unroll
+            for (uint32_t e = 0; e < 3u; ++e) {
+                float4 sphere;
+                float key;
+                lt_block_entry(lt, lo[e], hi[e], sphere, key);
+                beyond = beyond || key > slack;
+                const bool pass = !beyond && !misses_bounding_sphere2(sphere, rsx, rsy, rsz, rdx, rdy, rdz, dd, g.pretest_alpha);
+                pm |= pass ? (1u << e) : 0u;
+            }
+            pm &= 0x7u << pos;  // (a block the lane comes back to: the entries before `pos` have been dealt with)
+            uint32_t stalled = 0u, back = 0u, parked = pend ? 1u : 0u;
+            while (pm != 0u) {  // the ids of the candidates that passed
+                const uint32_t e = (uint32_t)__builtin_ctz(pm);
+                const uint32_t k = table_at(lt.block_ids, 4u * b + e);
+                const bool dup = (k == done_k) || (parked != 0u && k == pend_k);
+                const bool wait = !dup && parked != 0u;   // one parking slot: wait for the exact tests, resume at this entry
+                const bool take = !dup && parked == 0u;
+                pend_k = take ? k : pend_k;
+                parked = take ? 1u : parked;
+                stalled = wait ? 1u : stalled;
+                back = wait ? e : back;
+                pm = wait ? 0u : (pm & (pm - 1u));
+            }
+            pend = parked != 0u;
+            stall = stalled != 0u;
+            over = !stall && (beyond || nxt == 0u);
+            cursor = stall ? (b | (back << 24)) : nxt;
+        } else if (walking) {
             const float4 a = table_at(rec, 2u * cursor);
             const float4 b = table_at(rec, 2u * cursor + 1u);
             const uint32_t k = __float_as_uint(b.x), nxt = __float_as_uint(b.y);
@@ -1398,6 +1453,29 @@ __device__ __forceinline__ bool last_light_blocked(const WfParams& w, Ray ray, u
     const float chk = ((ray.sx + ray.sy) + ray.sz) + ((ray.dx + ray.dy) + ray.dz);
     uint32_t tile;
     float cut;
+    if (w.ltiles.blocks_enabled && chk == chk && light_tile_of(w.ltiles, ray.sx, ray.sy, ray.sz, tile, cut)) {
+        // the tile's chain of 32-byte blocks, three candidates each (the head block sits in an L2-sized table)
+        const LightTiles& lt = w.ltiles;
+        const float dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
+        for (uint32_t b = tile;;) {
+            const uint4 q0 = table_at(lt.blocks, 2u * b), q1 = table_at(lt.blocks, 2u * b + 1u);
+            const uint32_t lo[3] = {q0.z, q1.x, q1.z}, hi[3] = {q0.w, q1.y, q1.w};
+#pragma unroll
+            for (uint32_t e = 0; e < 3u; ++e) {
+                float4 sphere;
+                float key;
+                lt_block_entry(lt, lo[e], hi[e], sphere, key);
+                if (key > cut) return false;  // sorted by distance from the light: this entry and all after it lie beyond the ray's origin
+                if (misses_bounding_sphere2(sphere, ray.sx, ray.sy, ray.sz, ray.dx, ray.dy, ray.dz, dd, w.grid.pretest_alpha)) continue;
+                float t;
+                bool sphere_type;
+                ++tests;
+                if (lane_candidate<FUSED, true, true>(hot + table_at(lt.block_ids, 4u * b + e), ray, t, sphere_type) && !(t >= 1.f)) return true;
+            }
+            if (q0.x == 0u) return false;
+            b = q0.x;
+        }
+    }
     if (chk == chk && light_tile_of(w.ltiles, ray.sx, ray.sy, ray.sz, tile, cut)) {
         const float dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
         const uint2 range = table_at(w.ltiles.tile_range, tile);
@@ -1957,7 +2035,7 @@ static void launch_persistent(const WfParams& w, uint64_t n_max, uint32_t* ticke
         return;
     }
     const bool walk2_allowed = !walk2_env || (ANY ? std::strcmp(walk2_env, "any") == 0 : std::strcmp(walk2_env, "closest") == 0) || std::strcmp(walk2_env, "both") == 0;
-    if (!tri && w.grid.walk_rec && walk2_allowed && (!ANY || !w.ltiles.enabled || w.ltiles.walk_base != 0u)) {
+    if (!tri && w.grid.walk_rec && walk2_allowed && (!ANY || !w.ltiles.enabled || w.ltiles.walk_base != 0u || w.ltiles.blocks_enabled)) {
         if (w.count_rays) hipLaunchKernelGGL((wf_walk<FUSED, ANY, true>), grid, block, 0, s, w, ticket);
         else hipLaunchKernelGGL((wf_walk<FUSED, ANY, false>), grid, block, 0, s, w, ticket);
         return;
