@@ -1293,7 +1293,12 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
     }
     if (!(U1 > U0) || !(V1 > V0) || !std::isfinite(U0 + U1 + V0 + V1)) return RT_OK;
     // tile count: ~1.6 sqrt(n) per axis, halved while the lists would hold more than 24 entries per object
-    uint32_t T = (uint32_t)std::min(1024.0, std::max(16.0, 1.6 * std::sqrt((double)n)));
+    double tile_factor = 1.6;
+    if (const char* env = std::getenv("RT_LT_TILE_FACTOR")) {  // tuning knob (results do not depend on it)
+        const double v = std::atof(env);
+        if (v >= 0.1 && v <= 8.0) tile_factor = v;
+    }
+    uint32_t T = (uint32_t)std::min(1024.0, std::max(16.0, tile_factor * std::sqrt((double)n)));
     std::vector<uint32_t> start, entries, fill;
     uint64_t total = 0;
     float u0f = 0, v0f = 0, inv_du = 0, inv_dv = 0;
@@ -1458,7 +1463,7 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
                              T, T, (unsigned long long)total, blk.size() / 8, blk.size() / 8 - heads, (double)stepf, (double)rstepf, (double)kstepf);
         }
     }
-    if (!c->h_walk.empty() && total) {  // the same lists as records of the unified walk, each tile's chained to its end
+    if (!c->h_walk.empty() && total && !lt.blocks_enabled) {  // (no blocks - RT_NO_LT_BLOCKS: the lists as records of the unified walk, each tile's chained to its end)
         const uint64_t base = c->h_walk.size() / 2;
         if ((base + total) * 32ull < 0xf0000000ull) {
             c->h_walk.resize(2 * (size_t)(base + total));
