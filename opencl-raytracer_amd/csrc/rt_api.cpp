@@ -890,6 +890,38 @@ int build_walk_blocks(rt_context* c, uint32_t n, const std::vector<Bound>& sph, 
                 }
             }
     if ((uint64_t)blocks.size() * 4ull >= 0xf0000000ull) return RT_OK;
+    {   // Empty cells say how many FURTHER steps of a walk are sure to stay in empty cells: the Chebyshev distance to the nearest
+        // occupied cell minus one (a walk moves by one face per step), two-pass chamfer over the 26-neighbourhood of the padded
+        // array, capped at 63 - in the six header bits the chain pointer and the scale leave free (24-26 and 29-31). The walk takes
+        // those steps without fetching their blocks (a mesh leaves most of its grid empty: cfg5 walks 107 cells per ray).
+        const int nx = (int)wn[0], ny = (int)wn[1], nz = (int)wn[2];
+        std::vector<uint8_t> dist((size_t)n_cells);
+        for (size_t k = 0; k < (size_t)n_cells; ++k) dist[k] = (start[k + 1] - start[k]) ? 0 : 64;
+        auto at = [&](int x, int y, int z) -> uint8_t& { return dist[((size_t)z * ny + y) * nx + x]; };
+        for (int pass = 0; pass < 2; ++pass) {
+            const int dz = pass ? -1 : 1;
+            for (int z = pass ? nz - 1 : 0; z != (pass ? -1 : nz); z += dz)
+                for (int y = pass ? ny - 1 : 0; y != (pass ? -1 : ny); y += dz)
+                    for (int x = pass ? nx - 1 : 0; x != (pass ? -1 : nx); x += dz) {
+                        uint8_t& d = at(x, y, z);
+                        if (d == 0) continue;
+                        int best = d;
+                        for (int oz = -1; oz <= 0; ++oz)  // the 13 neighbours already visited in this scan direction
+                            for (int oy = -1; oy <= (oz ? 1 : 0); ++oy)
+                                for (int ox = -1; ox <= ((oz || oy) ? 1 : -1); ++ox) {
+                                    const int X = x + ox * dz, Y = y + oy * dz, Z = z + oz * dz;
+                                    if ((unsigned)X >= (unsigned)nx || (unsigned)Y >= (unsigned)ny || (unsigned)Z >= (unsigned)nz) continue;
+                                    best = std::min(best, (int)at(X, Y, Z) + 1);
+                                }
+                        d = (uint8_t)best;
+                    }
+        }
+        for (size_t k = 0; k < (size_t)n_cells; ++k) {
+            if (dist[k] < 2) continue;
+            const uint32_t skip = std::min<uint32_t>(63u, (uint32_t)dist[k] - 1u);
+            blocks[8 * k] |= ((skip & 7u) << 24) | ((skip >> 3) << 29);
+        }
+    }
     RT_HIP(c, hipMalloc((void**)&c->d_walk_blocks, sizeof(uint32_t) * blocks.size()));
     RT_HIP(c, hipMalloc((void**)&c->d_walk_ids, sizeof(uint32_t) * ids.size()));
     RT_HIP(c, hipMemcpy(c->d_walk_blocks, blocks.data(), sizeof(uint32_t) * blocks.size(), hipMemcpyHostToDevice));
@@ -1198,7 +1230,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     }
     g.pretest_alpha = std::nextafter((float)(6e-6 * K2 + 8e-6), std::numeric_limits<float>::infinity());
     g.enabled = 1u;
-    if (!c->has_triangles) {
+    if (!c->has_triangles || !std::getenv("RT_NO_TRI_BLOCKS")) {  // (meshes too since round 3: cfg5 56 -> 40 ms; the knob restores round 2's walk for them)
         StopWatch sw;
         const int rc = build_walk_blocks(c, n, sph, rg, cell, glo, ghi, K2);
         if (rc != RT_OK) return rc;
@@ -1383,7 +1415,7 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
     lt.light = li;
     lt.cut_pad = (float)std::max(1e-4, 4e-7 * (2.0 * coord_max + reach_max));
     lt.enabled = 1u;
-    if (!c->has_triangles && total && !std::getenv("RT_NO_LT_BLOCKS")) {
+    if ((!c->has_triangles || !std::getenv("RT_NO_TRI_BLOCKS")) && total && !std::getenv("RT_NO_LT_BLOCKS")) {
         // ... and as 32-byte blocks of three candidates (LightTiles::blocks). Lattice: 16 bits per axis over the grid box; every
         // sphere rounded outwards exactly as build_walk_blocks does it (the device's own fma for the centre, the known
         // quantisation error d added to the radius with the cross term of the distance-dependent tolerance:

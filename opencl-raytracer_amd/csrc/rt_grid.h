@@ -82,7 +82,8 @@ struct GridDesc {
 // dependent random fetch costs a CU ~5 cycles per line that misses L2 and ~3 per line that hits, whether 16 or 64 of
 // its bytes are used and whether 4 or 8 waves per SIMD are resident (tools/ubench/gather_rate.hip). So a fetch should
 // carry as many candidates as a line can hold. A SECOND, coarser grid over the same box, one 32-byte block per cell:
-//   word 0      header: next block of the cell's chain (bits 0-23, 0 = none), lattice scale s (bits 27-28)
+//   word 0      header: next block of the cell's chain (bits 0-23, 0 = none), lattice scale s (bits 27-28); an EMPTY cell's head:
+//               how many further steps of a walk are sure to stay in empty cells (bits 24-26 and 29-31: 0..63)
 //   words 1-7   one candidate each, its bounding sphere quantised to 8 bits per field {x, y, z, r} on a lattice of 256
 //               steps centred on the cell: step = 2^s cell / 128, i.e. scale 0 reaches half a cell beyond the cell on
 //               every side (unused slots: all zero - a sphere of radius 0 at a lattice corner; should a ray ever pass

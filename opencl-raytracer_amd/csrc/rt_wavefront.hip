@@ -419,6 +419,25 @@ constexpr uint32_t kTicketBase = 16;     // counts[16 ..]: closest-hit launch, c
 #define RT_DEFER_STUCK_SHIFT 2  // ... or once a quarter of the live lanes cannot move without theirs
 #endif
 
+// (the pre-test of rt_grid.h with the squared radius taken from the record; w2 = -inf: never passes)
+__device__ __forceinline__ bool misses_bounding_sphere2(const float4 s, float sx, float sy, float sz, float dx, float dy, float dz,
+                                                        float dd, float alpha) {
+    const float ox = s.x - sx, oy = s.y - sy, oz = s.z - sz;
+    const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
+    const float od = __builtin_fmaf(oz, dz, __builtin_fmaf(oy, dy, ox * dx));
+    const float c = oo - s.w;
+    const float disc = __builtin_fmaf(od, od, -(dd * __builtin_fmaf(-alpha, oo, c)));
+    return disc < 0.f || (od < 0.f && c > 1.0e-5f * oo);
+}
+
+// one candidate of a light-tile block (LightTiles::blocks): decoded sphere and distance key
+__device__ __forceinline__ void lt_block_entry(const LightTiles& lt, uint32_t lo, uint32_t hi, float4& sphere, float& key) {
+    const float r = (float)((hi >> 16) & 0xffu) * lt.rstep;
+    sphere = make_float4(__builtin_fmaf((float)(lo & 0xffffu), lt.lat_step, lt.lat_lox), __builtin_fmaf((float)(lo >> 16), lt.lat_step, lt.lat_loy),
+                         __builtin_fmaf((float)(hi & 0xffffu), lt.lat_step, lt.lat_loz), r * r);
+    key = (float)(hi >> 24) * lt.kstep;
+}
+
 // One segment of a queue, traced by one wave. A candidate that passes the 16-byte pre-test is not tested on the
 // spot: the lane parks it (`pend`) and keeps walking; the reference's exact test - a 52-byte gather and ~100
 // instructions - runs for the whole wave when enough lanes hold one (or are stuck behind theirs), so it executes
@@ -491,6 +510,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
     int idx = -1;
     bool cur_sphere = false;
     bool in_lt = false;    // shadow rays of the last light: the lane's list is a light tile (no cell walk: the list is all there is)
+    bool lt_blocks = false;  // ... in block form (LightTiles::blocks): the lane is in state 4
     bool pend = false;     // a candidate that passed the pre-test and awaits the exact test
     uint32_t pend_k = 0;   // ... its object, and the object of the last exact test: an object is registered in every cell its
     uint32_t done_k = 0xffffffffu;  // sphere reaches, so a ray meets it again in the next cell(s) - once is enough
@@ -518,6 +538,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                 }
                 ray.sw = 1.0f; ray.dw = 0.0f;  // what every ray of a grid-able frame carries (rt_create checks the preconditions)
                 in_lt = false;
+                lt_blocks = false;
                 // reflection rays: the object the ray leaves has had its exact test already (begin_shade_lit)
                 if (!ANY) done_k = (w.first_round == 0u) ? ray_light : 0xffffffffu;
                 T = kMaxFloat; idx = -1; cur_sphere = false; pend = false; if (ANY) done_k = 0xffffffffu;
@@ -541,10 +562,17 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                     const float chk = ((ray.sx + ray.sy) + ray.sz) + ((ray.dx + ray.dy) + ray.dz);
                     if (!done && chk == chk && light_tile_of(w.ltiles, ray.sx, ray.sy, ray.sz, tile, cut)) {
                         slack = cut;  // (the slot is free in this mode: no cell walk) how far from the light an occluder can start
-                        const uint2 range = table_at(w.ltiles.tile_range, tile);
-                        e = range.x;
-                        e1 = range.x + range.y;
-                        if (range.y != 0u) { w0.alive = true; in_lt = true; }
+                        if (w.ltiles.blocks_enabled) {  // the tile's chain of three-candidate blocks, head = block `tile` (state 4)
+                            e = tile;
+                            w0.alive = true;
+                            in_lt = true;
+                            lt_blocks = true;
+                        } else {
+                            const uint2 range = table_at(w.ltiles.tile_range, tile);
+                            e = range.x;
+                            e1 = range.x + range.y;
+                            if (range.y != 0u) { w0.alive = true; in_lt = true; }
+                        }
                     }
                 } else if (!done) {
                     w0 = walk_begin(g, ray, ANY ? 1.0f + slack : 3.0e38f);
@@ -554,7 +582,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
                     if (ANY) U(w, F_RES_ANY, pix) = (done || nan_shadow_blocked(w.rp.scene, ray)) ? 0u : 1u;
                     else store_closest_result(w, pix, T, idx);
                 } else {
-                    st = in_lt ? 2 : 1;
+                    st = lt_blocks ? 4 : (in_lt ? 2 : 1);
                 }
             }
             next += (uint32_t)__popcll(idle);
@@ -566,6 +594,44 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             continue;
         }
         bool advance = false, blocked = false;
+        if (ANY && st == 4) {
+            // ---- a light tile's block (state 4): three candidates per 32-byte fetch, as walk_segment's light-tile lanes ----
+            const LightTiles& lt = w.ltiles;
+            const uint32_t b = e & 0xffffffu, pos = e >> 24;
+            const uint4 q0 = table_at(lt.blocks, 2u * b), q1 = table_at(lt.blocks, 2u * b + 1u);
+            const uint32_t nxt = q0.x;
+            const uint32_t lo[3] = {q0.z, q1.x, q1.z}, hi[3] = {q0.w, q1.y, q1.w};
+            uint32_t pm = 0u;
+            bool beyond = false;  // sorted by distance from the light: an entry beyond the ray's origin ends the list
+#pragma unroll
+            for (uint32_t j = 0; j < 3u; ++j) {
+                float4 sphere;
+                float key;
+                lt_block_entry(lt, lo[j], hi[j], sphere, key);
+                beyond = beyond || key > slack;
+                if (STATS) ++s_pre;
+                const bool pass = !beyond && !misses_bounding_sphere2(sphere, ray.sx, ray.sy, ray.sz, ray.dx, ray.dy, ray.dz, dd, g.pretest_alpha);
+                pm |= pass ? (1u << j) : 0u;
+            }
+            pm &= 0x7u << pos;  // (a block the lane comes back to: the entries before `pos` have been dealt with)
+            uint32_t stalled = 0u, back = 0u, parked = pend ? 1u : 0u;
+            while (pm != 0u) {  // the ids of the candidates that passed
+                const uint32_t j = (uint32_t)__builtin_ctz(pm);
+                const uint32_t k = table_at(lt.block_ids, 4u * b + j);
+                const bool dup = (k == done_k) || (parked != 0u && k == pend_k);
+                const bool wait = !dup && parked != 0u;   // one parking slot: wait for the exact tests, resume at this entry
+                const bool take = !dup && parked == 0u;
+                pend_k = take ? k : pend_k;
+                parked = take ? 1u : parked;
+                stalled = wait ? 1u : stalled;
+                back = wait ? j : back;
+                pm = wait ? 0u : (pm & (pm - 1u));
+            }
+            pend = parked != 0u;
+            blocked = stalled != 0u;
+            st = (!blocked && (beyond || nxt == 0u)) ? 3 : 4;
+            e = blocked ? (b | (back << 24)) : nxt;
+        }
         uint32_t skip = 0u;
         // how many of those a lane takes in one trip: few while the wave is full (the other lanes wait for it), all of them
         // once it is nearly empty - the end of a launch is a handful of rays on their way out of the scene, ~100 dependent
@@ -732,24 +798,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRI ? RT_WA
 #define RT_WALK2_DEFER_PENDING RT_DEFER_PENDING
 #endif
 
-// (the pre-test of rt_grid.h with the squared radius taken from the record; w2 = -inf: never passes)
-__device__ __forceinline__ bool misses_bounding_sphere2(const float4 s, float sx, float sy, float sz, float dx, float dy, float dz,
-                                                        float dd, float alpha) {
-    const float ox = s.x - sx, oy = s.y - sy, oz = s.z - sz;
-    const float oo = __builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox));
-    const float od = __builtin_fmaf(oz, dz, __builtin_fmaf(oy, dy, ox * dx));
-    const float c = oo - s.w;
-    const float disc = __builtin_fmaf(od, od, -(dd * __builtin_fmaf(-alpha, oo, c)));
-    return disc < 0.f || (od < 0.f && c > 1.0e-5f * oo);
-}
 
-// one candidate of a light-tile block (LightTiles::blocks): decoded sphere and distance key
-__device__ __forceinline__ void lt_block_entry(const LightTiles& lt, uint32_t lo, uint32_t hi, float4& sphere, float& key) {
-    const float r = (float)((hi >> 16) & 0xffu) * lt.rstep;
-    sphere = make_float4(__builtin_fmaf((float)(lo & 0xffffu), lt.lat_step, lt.lat_lox), __builtin_fmaf((float)(lo >> 16), lt.lat_step, lt.lat_loy),
-                         __builtin_fmaf((float)(hi & 0xffffu), lt.lat_step, lt.lat_loz), r * r);
-    key = (float)(hi >> 24) * lt.kstep;
-}
 
 template <bool FUSED, bool ANY, bool STATS>
 __device__ __forceinline__ void walk_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue,
@@ -1050,6 +1099,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK2_WA
 #ifndef RT_WALK3_WAVES
 #define RT_WALK3_WAVES 6
 #endif
+#ifndef RT_BLOCK_SKIP_CAP
+#define RT_BLOCK_SKIP_CAP 8   // empty-space steps a lane takes per trip beyond the first (the other lanes of the wave wait for it)
+#endif
 
 #ifndef RT_LATTICE_BEHIND
 #define RT_LATTICE_BEHIND 0  // 1: also reject spheres entirely behind the origin (3 more instructions per candidate, ~15 % fewer exact tests: cfg4 +0.33 ms)
@@ -1079,7 +1131,7 @@ __device__ __forceinline__ uint32_t lattice_pretest(uint32_t pm, uint32_t word, 
 #endif
 }
 
-template <bool FUSED, bool STATS>
+template <bool FUSED, bool STATS, bool TRI>
 __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue,
                                               uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr,
                                               unsigned long long& tested) {
@@ -1181,7 +1233,7 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
                         const int k = brute ? (int)a : (int)g.always[a];
                         float t;
                         bool sphere;
-                        const bool cand = lane_candidate<FUSED, true, false>(hot + k, ray, t, sphere);
+                        const bool cand = lane_candidate<FUSED, true, TRI>(hot + k, ray, t, sphere);
                         if (STATS) ++tested;
                         if (cand) closest_take(t, k, sphere, T, idx, cur_sphere);
                     }
@@ -1250,6 +1302,26 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
             fy += (adv && ay) ? __builtin_copysignf(1.0f, rdy) : 0.f;
             fz += (adv && az) ? __builtin_copysignf(1.0f, rdz) : 0.f;
             fl |= (adv && tmin > limit) ? kOver : 0u;
+            {   // empty space: an empty cell's header says how many further steps stay in empty cells - taken here without fetching
+                // their blocks (same cells, same order, same end test; at most RT_BLOCK_SKIP_CAP per trip: the other lanes wait)
+                uint32_t more = ((q0.x >> 24) & 7u) | ((q0.x >> 26) & 0x38u);
+                more = (adv && (fl & kOver) == 0u) ? (more < (uint32_t)RT_BLOCK_SKIP_CAP ? more : (uint32_t)RT_BLOCK_SKIP_CAP) : 0u;
+                while (more != 0u) {
+                    const float tm = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+                    const bool sx = (tx <= ty) && (tx <= tz);
+                    const bool sy = !sx && (ty <= tz);
+                    const bool sz = !sx && !sy;
+                    tx += sx ? dtx : 0.f;
+                    ty += sy ? dty : 0.f;
+                    tz += sz ? dtz : 0.f;
+                    fx += sx ? __builtin_copysignf(1.0f, rdx) : 0.f;
+                    fy += sy ? __builtin_copysignf(1.0f, rdy) : 0.f;
+                    fz += sz ? __builtin_copysignf(1.0f, rdz) : 0.f;
+                    const bool out = tm > limit;
+                    fl |= out ? kOver : 0u;
+                    more = out ? 0u : more - 1u;
+                }
+            }
             const uint32_t cell = (uint32_t)__builtin_fmaf(__builtin_fmaf(fz, wny_f, fy), wnx_f, fx);  // (whole numbers below 2^24: exact)
             cur = stalled != 0u ? (b | (back << 24)) : (adv ? cell : nxt);
         }
@@ -1265,7 +1337,7 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
                     float t;
                     bool sphere;
                     const Ray ray = {rsx, rsy, rsz, 1.0f, rdx, rdy, rdz, 0.0f};
-                    const bool cand = lane_candidate<FUSED, true, false>(hot + pend_k, ray, t, sphere);
+                    const bool cand = lane_candidate<FUSED, true, TRI>(hot + pend_k, ray, t, sphere);
                     if (STATS) ++tested;
                     done_k = pend_k;
                     bool cur_sphere = (fl & kSphere) != 0u;
@@ -1292,7 +1364,7 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
     }
 }
 
-template <bool FUSED, bool STATS>
+template <bool FUSED, bool STATS, bool TRI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK3_WAVES))) void wf_walk_blocks(const WfParams wk, uint32_t* __restrict__ run_ctr) {
     WfParams w = wk;
     if (!resolve_round(w)) return;
@@ -1301,7 +1373,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK3_WA
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * 256u) >> 6;
     unsigned long long tested = 0;
-    block_segment<FUSED, STATS>(w, w.q_prev_closest, n_queue, wave, n_waves, run_ctr, tested);
+    block_segment<FUSED, STATS, TRI>(w, w.q_prev_closest, n_queue, wave, n_waves, run_ctr, tested);
     if (STATS && tested) atomicAdd(&w.rp.counters->tests, tested);
 }
 
@@ -2029,9 +2101,14 @@ static void launch_persistent(const WfParams& w, uint64_t n_max, uint32_t* ticke
     // none picks which of the two walks use it (measurement knob)
     const char* walk2_env = std::getenv("RT_WALK2");  // (read per launch: tests switch walks inside one process)
     const char* walk3_env = std::getenv("RT_WALK3");  // "0": closest-hit rays through walk_segment / trace_segment instead
-    if (!ANY && !tri && w.bgrid.enabled && !(walk3_env && walk3_env[0] == '0')) {
-        if (w.count_rays) hipLaunchKernelGGL((wf_walk_blocks<FUSED, true>), grid, block, 0, s, w, ticket);
-        else hipLaunchKernelGGL((wf_walk_blocks<FUSED, false>), grid, block, 0, s, w, ticket);
+    if (!ANY && w.bgrid.enabled && !(walk3_env && walk3_env[0] == '0')) {
+        if (tri) {  // (meshes: the same walk with the triangle branch in its exact tests)
+            if (w.count_rays) hipLaunchKernelGGL((wf_walk_blocks<FUSED, true, true>), grid, block, 0, s, w, ticket);
+            else hipLaunchKernelGGL((wf_walk_blocks<FUSED, false, true>), grid, block, 0, s, w, ticket);
+        } else {
+            if (w.count_rays) hipLaunchKernelGGL((wf_walk_blocks<FUSED, true, false>), grid, block, 0, s, w, ticket);
+            else hipLaunchKernelGGL((wf_walk_blocks<FUSED, false, false>), grid, block, 0, s, w, ticket);
+        }
         return;
     }
     const bool walk2_allowed = !walk2_env || (ANY ? std::strcmp(walk2_env, "any") == 0 : std::strcmp(walk2_env, "closest") == 0) || std::strcmp(walk2_env, "both") == 0;
