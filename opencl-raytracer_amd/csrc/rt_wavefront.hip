@@ -1364,6 +1364,71 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
     }
 }
 
+// The same walk for ONE ray in one thread (wf_finish: the tail of a frame, where a ray's time is its chain of dependent
+// fetches - cfg5: 28 blocks + the empty-space steps their headers allow, against 64 cells of the fine grid). Same blocks, same
+// pre-test, same exact tests, order-free update: the result of closest_hit_grid. False: not this walk's kind of ray
+// (block_segment's `tame`), nothing was done.
+template <bool FUSED>
+__device__ __forceinline__ bool closest_hit_blocks(const BlockGrid& bg, const GridDesc& g, const HotObject* __restrict__ hot, const Ray& ray,
+                                                   uint32_t skip_object, float& T, int& index, uint32_t& tested) {
+    const float dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
+    const Walk w0 = walk_begin(bg, ray, 3.0e38f);
+    if (!w0.alive) return true;  // misses the grid box, or a NaN in it: no candidates (closest_result patches NaN rays)
+    const float dmin = __builtin_fminf(__builtin_fminf(w0.dtx, w0.dty), w0.dtz);
+    if (!(dd > 1.0e-30f && dd < 1.0e30f && w0.t_enter <= 4096.f * dmin)) return false;
+    const float slack = kWalkSlackCells * bg.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f;
+    const float t_stop = __builtin_fminf(w0.t_exit + 0.25f * dmin, 3.0e38f);
+    float fx = (float)(w0.ix + (int)kBlockBorder), fy = (float)(w0.iy + (int)kBlockBorder), fz = (float)(w0.iz + (int)kBlockBorder);
+    float tx = w0.tx, ty = w0.ty, tz = w0.tz;
+    const float wnx_f = (float)bg.wnx, wny_f = (float)bg.wny;
+    const float neg_dd = -dd, oma = 1.0f - g.pretest_alpha;
+    bool cur_sphere = false;
+    uint32_t done_k = skip_object;
+    uint32_t b = (uint32_t)__builtin_fmaf(__builtin_fmaf(fz, wny_f, fy), wnx_f, fx);
+    for (;;) {
+        const uint4 q0 = table_at(bg.blocks, 2u * b);
+        const uint4 q1 = table_at(bg.blocks, 2u * b + 1u);
+        const float inv = __builtin_ldexpf(bg.inv_step, -(int)((q0.x >> 27) & 3u));
+        const float olx = __builtin_fmaf(ray.sx - __builtin_fmaf(fx, bg.cell, bg.c0x), inv, 128.0f);
+        const float oly = __builtin_fmaf(ray.sy - __builtin_fmaf(fy, bg.cell, bg.c0y), inv, 128.0f);
+        const float olz = __builtin_fmaf(ray.sz - __builtin_fmaf(fz, bg.cell, bg.c0z), inv, 128.0f);
+        uint32_t pm = 0u;
+        if constexpr (kBlockEntries > 6) pm = lattice_pretest(pm, q1.w, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        if constexpr (kBlockEntries > 5) pm = lattice_pretest(pm, q1.z, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        if constexpr (kBlockEntries > 4) pm = lattice_pretest(pm, q1.y, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        if constexpr (kBlockEntries > 3) pm = lattice_pretest(pm, q1.x, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        if constexpr (kBlockEntries > 2) pm = lattice_pretest(pm, q0.w, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        if constexpr (kBlockEntries > 1) pm = lattice_pretest(pm, q0.z, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        pm = lattice_pretest(pm, q0.y, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        while (pm != 0u) {
+            const uint32_t k = table_at(bg.ids, 8u * b + (uint32_t)__builtin_ctz(pm));
+            pm &= pm - 1u;
+            if (k == done_k) continue;  // tested a moment ago (the same object in the next cell; a reflection ray's own object)
+            done_k = k;
+            float t;
+            bool sphere;
+            ++tested;
+            if (lane_candidate<FUSED, true, true>(hot + k, ray, t, sphere)) closest_take(t, (int)k, sphere, T, index, cur_sphere);
+        }
+        const uint32_t nxt = q0.x & 0xffffffu;
+        if (nxt != 0u) { b = nxt; continue; }
+        uint32_t steps = 1u + (((q0.x >> 24) & 7u) | ((q0.x >> 26) & 0x38u));  // (an empty cell: + the steps sure to stay in empty cells)
+        bool stop = false;
+        const float limit = __builtin_fminf(T + slack, t_stop);
+        while (steps-- != 0u && !stop) {
+            const float tmin = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+            stop = tmin > limit;
+            if (stop) break;
+            if (tx <= ty && tx <= tz) { tx += w0.dtx; fx += __builtin_copysignf(1.0f, ray.dx); }
+            else if (ty <= tz) { ty += w0.dty; fy += __builtin_copysignf(1.0f, ray.dy); }
+            else { tz += w0.dtz; fz += __builtin_copysignf(1.0f, ray.dz); }
+        }
+        if (stop) break;
+        b = (uint32_t)__builtin_fmaf(__builtin_fmaf(fz, wny_f, fy), wnx_f, fx);
+    }
+    return true;
+}
+
 template <bool FUSED, bool STATS, bool TRI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK3_WAVES))) void wf_walk_blocks(const WfParams wk, uint32_t* __restrict__ run_ctr) {
     WfParams w = wk;
@@ -2001,10 +2066,16 @@ __global__ __launch_bounds__(256) void wf_finish(const WfParams wk) {
                     U(w, F_RES_ANY, c.i) = blocked ? 0u : 1u;
                 }
                 if (do_closest) {
-                    const Ray ray = load_ray(w, c.i, kSlotClosest);
+                    Ray ray = load_ray(w, c.i, kSlotClosest);
                     float T = kMaxFloat;
                     int idx = -1;
-                    closest_hit_grid<FUSED, true>(w.grid, w.rp.scene.hot, ray, T, idx, tested);
+                    bool walked = false;
+                    if (w.bgrid.enabled && w.grid.n_always == 0u) {  // the block grid (the ray's note names the object it leaves)
+                        const uint32_t note = __float_as_uint(ray.dw);
+                        ray.sw = 1.0f; ray.dw = 0.0f;
+                        walked = closest_hit_blocks<FUSED>(w.bgrid, w.grid, w.rp.scene.hot, ray, note, T, idx, tested);
+                    }
+                    if (!walked) closest_hit_grid<FUSED, true>(w.grid, w.rp.scene.hot, ray, T, idx, tested);
                     store_closest_result(w, c.i, T, idx);
                 }
                 c.want_closest = false;
