@@ -98,3 +98,37 @@ def test_three_closest_hit_walks_agree_on_a_reflecting_frame(monkeypatch):
     for name in ("records", "round2", "brute"):
         assert np.array_equal(frames["blocks"].view(np.uint32), frames[name].view(np.uint32)), name
         assert frames["blocks_rays"] == frames[name + "_rays"], name
+
+
+def test_meshes_block_walk_equals_the_round2_walk(monkeypatch):
+    """Triangles (the extension) have no brute-force path to compare with; their block walk - triangle branch in the exact tests,
+    empty-space steps from the block headers, light tiles in block form - is held against round 2's walk (RT_NO_TRI_BLOCKS), which
+    tests/test_triangles_gpu.py pins to the CPU statement: same frame, same ray counts, bit for bit."""
+    from opencl_raytracer_amd import scene_loader, tessellate
+    from helpers import SCENES
+    objs, lights = scene_loader.load_scene(str(SCENES / "roundedCube.txt"))
+    mesh = tessellate.tessellate(objs, 24, 48, 20)
+    rng = np.random.default_rng(23)
+    extra = []                                 # analytic spheres / boxes among the triangles
+    for k in range(120):
+        mv, inv = instance(rng.uniform([-4, -4, -14], [4, 4, -6]), rotation(rng.normal(size=3), rng.uniform(0, 6)), np.full(3, rng.uniform(0.1, 0.4)))
+        mat = R.Material(ambient=rng.uniform(0, 1, 3), diffuse=rng.uniform(0, 1, 3), specular=rng.uniform(0, 1, 3),
+                         absorption=float(rng.choice([1.0, 0.4])), reflection=0.0, shininess=8.0)
+        extra.append(R.make_object(R.BOX if k % 3 == 0 else R.SPHERE, mat, mv, inv))
+    extra = R.objects_array(extra)
+    scene = np.concatenate([mesh, extra])
+    W, H = 192, 144
+    z = float(camera.camera_z(H))
+    frames = {}
+    for name, env in (("blocks", None), ("round2", "1")):
+        monkeypatch.delenv("RT_NO_TRI_BLOCKS", raising=False)
+        if env:
+            monkeypatch.setenv("RT_NO_TRI_BLOCKS", env)
+        with hip(scene, lights, None, 5, camera=(W, H, z)) as rt:
+            frames[name] = rt.Render()
+            st = rt.count_rays()
+            assert st.wavefront == 1
+            frames[name + "_rays"] = (st.rays_reference, st.rays_traced, st.hit_pixels)
+    assert frames["blocks_rays"] == frames["round2_rays"]
+    assert frames["blocks_rays"][2] > 2000
+    assert np.array_equal(frames["blocks"].view(np.uint32), frames["round2"].view(np.uint32))
