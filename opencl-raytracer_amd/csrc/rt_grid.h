@@ -108,6 +108,8 @@ struct BlockGrid {
     const uint32_t* __restrict__ ids;   // 8 per block (slot e of block b: ids[8 b + e]; slot 7 unused)
     uint32_t none;             // the never-hit dummy object
     uint32_t enabled;
+    uint32_t take_skips;       // the walk takes the empty-space steps of the headers (always set; RT_BLOCK_SKIPS=0 is the measurement knob:
+                               // cfg4 12.2 -> 12.4 ms, cfg5 40 -> 48 ms without them)
 };
 constexpr uint32_t kBlockBorder = 2;
 #ifndef RT_BLOCK_ENTRIES

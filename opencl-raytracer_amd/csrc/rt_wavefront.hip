@@ -1306,6 +1306,7 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
                 // their blocks (same cells, same order, same end test; at most RT_BLOCK_SKIP_CAP per trip: the other lanes wait)
                 uint32_t more = ((q0.x >> 24) & 7u) | ((q0.x >> 26) & 0x38u);
                 more = (adv && (fl & kOver) == 0u) ? (more < (uint32_t)RT_BLOCK_SKIP_CAP ? more : (uint32_t)RT_BLOCK_SKIP_CAP) : 0u;
+                if (!bg.take_skips) more = 0u;  // (wave-uniform: crowded grids do not bother)
                 while (more != 0u) {
                     const float tm = __builtin_fminf(__builtin_fminf(tx, ty), tz);
                     const bool sx = (tx <= ty) && (tx <= tz);
