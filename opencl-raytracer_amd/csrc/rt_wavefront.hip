@@ -1430,6 +1430,67 @@ __device__ __forceinline__ bool closest_hit_blocks(const BlockGrid& bg, const Gr
     return true;
 }
 
+// ... and "is anything in the way before t = 1" for one shadow ray in one thread (wf_finish: the light scans of the frame's
+// tail go to lights that have no tiles). Same answer as any_hit_grid. `done`: false = not this walk's kind of ray.
+template <bool FUSED>
+__device__ __forceinline__ bool any_hit_blocks(const BlockGrid& bg, const GridDesc& g, const HotObject* __restrict__ hot, const Ray& ray,
+                                               bool& done, uint32_t& tested) {
+    done = true;
+    const float dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
+    const float slack = dd > 0.f ? kWalkSlackCells * bg.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
+    const Walk w0 = walk_begin(bg, ray, 1.0f + slack);
+    if (!w0.alive) { done = false; return false; }  // (off the grid or a NaN ray: the caller's any_hit_grid knows what that means)
+    const float dmin = __builtin_fminf(__builtin_fminf(w0.dtx, w0.dty), w0.dtz);
+    if (!(dd > 1.0e-30f && dd < 1.0e30f && w0.t_enter <= 4096.f * dmin)) { done = false; return false; }
+    const float limit = __builtin_fminf(w0.t_exit + 0.25f * dmin, 3.0e38f);  // (t_exit <= 1 + slack already)
+    float fx = (float)(w0.ix + (int)kBlockBorder), fy = (float)(w0.iy + (int)kBlockBorder), fz = (float)(w0.iz + (int)kBlockBorder);
+    float tx = w0.tx, ty = w0.ty, tz = w0.tz;
+    const float wnx_f = (float)bg.wnx, wny_f = (float)bg.wny;
+    const float neg_dd = -dd, oma = 1.0f - g.pretest_alpha;
+    uint32_t done_k = 0xffffffffu;
+    uint32_t b = (uint32_t)__builtin_fmaf(__builtin_fmaf(fz, wny_f, fy), wnx_f, fx);
+    for (;;) {
+        const uint4 q0 = table_at(bg.blocks, 2u * b);
+        const uint4 q1 = table_at(bg.blocks, 2u * b + 1u);
+        const float inv = __builtin_ldexpf(bg.inv_step, -(int)((q0.x >> 27) & 3u));
+        const float olx = __builtin_fmaf(ray.sx - __builtin_fmaf(fx, bg.cell, bg.c0x), inv, 128.0f);
+        const float oly = __builtin_fmaf(ray.sy - __builtin_fmaf(fy, bg.cell, bg.c0y), inv, 128.0f);
+        const float olz = __builtin_fmaf(ray.sz - __builtin_fmaf(fz, bg.cell, bg.c0z), inv, 128.0f);
+        uint32_t pm = 0u;
+        if constexpr (kBlockEntries > 6) pm = lattice_pretest(pm, q1.w, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        if constexpr (kBlockEntries > 5) pm = lattice_pretest(pm, q1.z, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        if constexpr (kBlockEntries > 4) pm = lattice_pretest(pm, q1.y, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        if constexpr (kBlockEntries > 3) pm = lattice_pretest(pm, q1.x, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        if constexpr (kBlockEntries > 2) pm = lattice_pretest(pm, q0.w, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        if constexpr (kBlockEntries > 1) pm = lattice_pretest(pm, q0.z, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        pm = lattice_pretest(pm, q0.y, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        while (pm != 0u) {
+            const uint32_t k = table_at(bg.ids, 8u * b + (uint32_t)__builtin_ctz(pm));
+            pm &= pm - 1u;
+            if (k == done_k) continue;
+            done_k = k;
+            float t;
+            bool sphere;
+            ++tested;
+            if (lane_candidate<FUSED, true, true>(hot + k, ray, t, sphere) && !(t >= 1.f)) return true;
+        }
+        const uint32_t nxt = q0.x & 0xffffffu;
+        if (nxt != 0u) { b = nxt; continue; }
+        uint32_t steps = 1u + (((q0.x >> 24) & 7u) | ((q0.x >> 26) & 0x38u));
+        bool stop = false;
+        while (steps-- != 0u && !stop) {
+            const float tmin = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+            stop = tmin > limit;
+            if (stop) break;
+            if (tx <= ty && tx <= tz) { tx += w0.dtx; fx += __builtin_copysignf(1.0f, ray.dx); }
+            else if (ty <= tz) { ty += w0.dty; fy += __builtin_copysignf(1.0f, ray.dy); }
+            else { tz += w0.dtz; fz += __builtin_copysignf(1.0f, ray.dz); }
+        }
+        if (stop) return false;
+        b = (uint32_t)__builtin_fmaf(__builtin_fmaf(fz, wny_f, fy), wnx_f, fx);
+    }
+}
+
 template <bool FUSED, bool STATS, bool TRI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK3_WAVES))) void wf_walk_blocks(const WfParams wk, uint32_t* __restrict__ run_ctr) {
     WfParams w = wk;
@@ -2061,9 +2122,19 @@ __global__ __launch_bounds__(256) void wf_finish(const WfParams wk) {
                         ray = load_ray(w, c.i, kSlotShadow);
                         li = __float_as_uint(ray.dw);
                     }
-                    const bool blocked = (w.ltiles.enabled && li == w.ltiles.light)
-                                             ? last_light_blocked<FUSED>(w, ray, tested)   // (the walk's choice: trace_segment)
-                                             : any_hit_grid<FUSED>(w.grid, w.rp.scene, ray, tested);
+                    bool blocked;
+                    if (w.ltiles.enabled && li == w.ltiles.light) {
+                        blocked = last_light_blocked<FUSED>(w, ray, tested);   // (the walk's choice: trace_segment)
+                    } else {
+                        bool walked = false;
+                        blocked = false;
+                        if (w.bgrid.enabled && w.grid.n_always == 0u) {
+                            Ray r1 = ray;
+                            r1.sw = 1.0f; r1.dw = 0.0f;
+                            blocked = any_hit_blocks<FUSED>(w.bgrid, w.grid, w.rp.scene.hot, r1, walked, tested);
+                        }
+                        if (!walked) blocked = any_hit_grid<FUSED>(w.grid, w.rp.scene, ray, tested);
+                    }
                     U(w, F_RES_ANY, c.i) = blocked ? 0u : 1u;
                 }
                 if (do_closest) {
