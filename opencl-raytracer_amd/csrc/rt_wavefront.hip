@@ -438,42 +438,20 @@ __device__ __forceinline__ void lt_block_entry(const LightTiles& lt, uint32_t lo
     key = (float)(hi >> 24) * lt.kstep;
 }
 
-// One segment of a queue, traced by one wave. A candidate that passes the 16-byte pre-test is not tested on the
-// spot: the lane parks it (`pend`) and keeps walking; the reference's exact test - a 52-byte gather and ~100
-// instructions - runs for the whole wave when enough lanes hold one (or are stuck behind theirs), so it executes
-// with tens of lanes instead of the 3-5 that happen to need it in any single trip. The closest-hit update is
-// order-free and T only ever shrinks, so a late update can only make a lane look at MORE cells than necessary.
-template <bool FUSED, bool ANY, bool STATS, bool TRI>
-__device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue,
-                                              uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr,
-                                              unsigned long long& tested) {
-    const uint32_t lane = threadIdx.x & 63u;
-    // The queue is cut in runs of kSegment entries. Few runs: wave i traces run i. Many: the resident waves draw
-    // run after run from ONE ticket counter, in queue order - so the chip stays balanced to the end of the launch
-    // without the per-wave tails of long fixed segments, and the rays in flight at any moment are neighbours in the
-    // queue (= in the image), which is what keeps cells and objects in L2: drawing from 64 regions of the queue at
-    // once cost 62 ms per cfg4 frame, from one 46.5. Ticket demand (~26 per microsecond) is far below what one
-    // counter sustains (~88).
-    // Run length: kSegment while the queue holds at least two such runs per launched wave; shorter (down to 64) for
-    // small queues - the tail of a frame, or one rank's share of it on a multi-GPU node - so that every wave still gets
-    // work and no wave ends the launch alone with a long run.
-    uint32_t seg = kSegment;
-    while (seg > 64u && n_queue < 2u * n_waves * seg) seg >>= 1;
-    const uint32_t n_runs = (n_queue + seg - 1u) / seg;
-    const bool dynamic = n_runs > n_waves;
-    uint32_t next = 0, seg_end = 0;  // wave-uniform cursor into the current run
-    // Dynamic hand-out, XCD-affine: the queue is cut into kTicketRegions contiguous regions with one ticket counter
-    // each; a wave draws from the region of the XCD it runs on (HW_REG_XCC_ID - placement is only a speed matter)
-    // and moves on to the next region when its own is used up. Each XCD has its own L2: this way the rays in flight
-    // on one XCD are neighbours in the queue (= in the image), instead of a 1/8 sample of the whole chip's
-    // neighbourhood, so an XCD's L2 holds an eighth of the cells / spheres / matrices the chip is working on.
-    uint32_t region = 0, regions_tried = 0;
-    if (kTicketRegions > 1u) {
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        region = (xcc & 0xfu) % kTicketRegions;
-    }
-    auto grab = [&]() -> bool {
+// The queue of a persistent walk, cut in runs of `seg` entries (all three walks: trace_segment, walk_segment, block_segment).
+// Few runs: wave i traces run i. Many: the resident waves draw run after run from ticket counters, in queue order - so the
+// chip stays balanced to the end of the launch without the per-wave tails of long fixed segments, and the rays in flight at any
+// moment are neighbours in the queue (= in the image), which is what keeps cells and objects in L2. Run length: kSegment while
+// the queue holds at least two such runs per launched wave; shorter (down to 64) for small queues - the tail of a frame, or one
+// rank's share of it on a multi-GPU node - so that every wave still gets work and no wave ends the launch alone with a long run.
+// Dynamic hand-out is XCD-affine: the queue is cut into kTicketRegions contiguous regions with one ticket counter each; a wave
+// draws from the region of the XCD it runs on (HW_REG_XCC_ID - placement is only a speed matter) and moves on to the next
+// region when its own is used up. Each XCD has its own L2: this way the rays in flight on one XCD are neighbours in the queue.
+// (A single counter's returning atomics, ~88 per microsecond, were costing 1.6 ms per cfg4 frame at 128-entry runs.)
+struct RunCursor {
+    uint32_t seg, n_runs, next, seg_end, region, regions_tried;
+    bool dynamic;
+    __device__ __forceinline__ bool grab(uint32_t n_queue, uint32_t* __restrict__ run_ctr, uint32_t lane) {
         for (;;) {
             const uint32_t lo = (uint32_t)(((uint64_t)n_runs * region) / kTicketRegions);
             const uint32_t hi = (uint32_t)(((uint64_t)n_runs * (region + 1u)) / kTicketRegions);
@@ -488,15 +466,43 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             if (++regions_tried >= kTicketRegions) return false;
             region = (region + 1u == kTicketRegions) ? 0u : region + 1u;
         }
-    };
-    bool more = dynamic;  // may another run be drawn?
-    if (dynamic) {
-        if (!grab()) return;
-    } else {
-        if (wave >= n_runs) return;
+    }
+    // false: nothing for this wave to do
+    __device__ __forceinline__ bool begin(uint32_t n_queue, uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr, uint32_t lane) {
+        seg = kSegment;
+        while (seg > 64u && n_queue < 2u * n_waves * seg) seg >>= 1;
+        n_runs = (n_queue + seg - 1u) / seg;
+        dynamic = n_runs > n_waves;
+        next = 0; seg_end = 0; region = 0; regions_tried = 0;
+        if (kTicketRegions > 1u) {
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            region = (xcc & 0xfu) % kTicketRegions;
+        }
+        if (dynamic) return grab(n_queue, run_ctr, lane);
+        if (wave >= n_runs) return false;
         next = wave * seg;
         seg_end = (n_queue - next < seg) ? n_queue : next + seg;
+        return true;
     }
+};
+
+// One segment of a queue, traced by one wave. A candidate that passes the 16-byte pre-test is not tested on the
+// spot: the lane parks it (`pend`) and keeps walking; the reference's exact test - a 52-byte gather and ~100
+// instructions - runs for the whole wave when enough lanes hold one (or are stuck behind theirs), so it executes
+// with tens of lanes instead of the 3-5 that happen to need it in any single trip. The closest-hit update is
+// order-free and T only ever shrinks, so a late update can only make a lane look at MORE cells than necessary.
+template <bool FUSED, bool ANY, bool STATS, bool TRI>
+__device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue,
+                                              uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr,
+                                              unsigned long long& tested) {
+    const uint32_t lane = threadIdx.x & 63u;
+    RunCursor rc;   // runs of queue entries and their tickets (wave-uniform): see RunCursor
+    if (!rc.begin(n_queue, wave, n_waves, run_ctr, lane)) return;
+    uint32_t& next = rc.next;
+    const uint32_t& seg_end = rc.seg_end;
+    auto grab = [&]() -> bool { return rc.grab(n_queue, run_ctr, lane); };
+    bool more = rc.dynamic;  // may another run be drawn?
     const GridDesc& g = w.grid;
     const HotObject* __restrict__ hot = w.rp.scene.hot;
 
@@ -805,42 +811,12 @@ __device__ __forceinline__ void walk_segment(const WfParams& w, const uint32_t* 
                                              uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr,
                                              unsigned long long& tested) {
     const uint32_t lane = threadIdx.x & 63u;
-    // runs and tickets: as trace_segment
-    uint32_t seg = kSegment;
-    while (seg > 64u && n_queue < 2u * n_waves * seg) seg >>= 1;
-    const uint32_t n_runs = (n_queue + seg - 1u) / seg;
-    const bool dynamic = n_runs > n_waves;
-    uint32_t next = 0, seg_end = 0;
-    uint32_t region = 0, regions_tried = 0;
-    if (kTicketRegions > 1u) {
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        region = (xcc & 0xfu) % kTicketRegions;
-    }
-    auto grab = [&]() -> bool {
-        for (;;) {
-            const uint32_t lo = (uint32_t)(((uint64_t)n_runs * region) / kTicketRegions);
-            const uint32_t hi = (uint32_t)(((uint64_t)n_runs * (region + 1u)) / kTicketRegions);
-            uint32_t r = 0;
-            if (lane == 0u) r = atomicAdd(run_ctr + region * kTicketStride, 1u);
-            r = __builtin_amdgcn_readfirstlane(r) + lo;
-            if (r < hi) {
-                next = r * seg;
-                seg_end = (n_queue - next < seg) ? n_queue : next + seg;
-                return true;
-            }
-            if (++regions_tried >= kTicketRegions) return false;
-            region = (region + 1u == kTicketRegions) ? 0u : region + 1u;
-        }
-    };
-    bool more = dynamic;
-    if (dynamic) {
-        if (!grab()) return;
-    } else {
-        if (wave >= n_runs) return;
-        next = wave * seg;
-        seg_end = (n_queue - next < seg) ? n_queue : next + seg;
-    }
+    RunCursor rc;   // runs of queue entries and their tickets (wave-uniform)
+    if (!rc.begin(n_queue, wave, n_waves, run_ctr, lane)) return;
+    uint32_t& next = rc.next;
+    const uint32_t& seg_end = rc.seg_end;
+    auto grab = [&]() -> bool { return rc.grab(n_queue, run_ctr, lane); };
+    bool more = rc.dynamic;
     const GridDesc& g = w.grid;
     const HotObject* __restrict__ hot = w.rp.scene.hot;
     const float4* __restrict__ rec = g.walk_rec;
@@ -1136,42 +1112,12 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
                                               uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr,
                                               unsigned long long& tested) {
     const uint32_t lane = threadIdx.x & 63u;
-    // runs and tickets: as trace_segment
-    uint32_t seg = kSegment;
-    while (seg > 64u && n_queue < 2u * n_waves * seg) seg >>= 1;
-    const uint32_t n_runs = (n_queue + seg - 1u) / seg;
-    const bool dynamic = n_runs > n_waves;
-    uint32_t next = 0, seg_end = 0;
-    uint32_t region = 0, regions_tried = 0;
-    if (kTicketRegions > 1u) {
-        uint32_t xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        region = (xcc & 0xfu) % kTicketRegions;
-    }
-    auto grab = [&]() -> bool {
-        for (;;) {
-            const uint32_t lo = (uint32_t)(((uint64_t)n_runs * region) / kTicketRegions);
-            const uint32_t hi = (uint32_t)(((uint64_t)n_runs * (region + 1u)) / kTicketRegions);
-            uint32_t r = 0;
-            if (lane == 0u) r = atomicAdd(run_ctr + region * kTicketStride, 1u);
-            r = __builtin_amdgcn_readfirstlane(r) + lo;
-            if (r < hi) {
-                next = r * seg;
-                seg_end = (n_queue - next < seg) ? n_queue : next + seg;
-                return true;
-            }
-            if (++regions_tried >= kTicketRegions) return false;
-            region = (region + 1u == kTicketRegions) ? 0u : region + 1u;
-        }
-    };
-    bool more = dynamic;
-    if (dynamic) {
-        if (!grab()) return;
-    } else {
-        if (wave >= n_runs) return;
-        next = wave * seg;
-        seg_end = (n_queue - next < seg) ? n_queue : next + seg;
-    }
+    RunCursor rc;   // runs of queue entries and their tickets (wave-uniform)
+    if (!rc.begin(n_queue, wave, n_waves, run_ctr, lane)) return;
+    uint32_t& next = rc.next;
+    const uint32_t& seg_end = rc.seg_end;
+    auto grab = [&]() -> bool { return rc.grab(n_queue, run_ctr, lane); };
+    bool more = rc.dynamic;
     const GridDesc& g = w.grid;
     const BlockGrid& bg = w.bgrid;
     const HotObject* __restrict__ hot = w.rp.scene.hot;
@@ -1491,8 +1437,11 @@ __device__ __forceinline__ bool any_hit_blocks(const BlockGrid& bg, const GridDe
     }
 }
 
+#ifndef RT_WALK3_WAVES_TRI
+#define RT_WALK3_WAVES_TRI RT_WALK3_WAVES   // the variant with the triangle branch wants ~95 registers: 6 waves = 17 spilled
+#endif
 template <bool FUSED, bool STATS, bool TRI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK3_WAVES))) void wf_walk_blocks(const WfParams wk, uint32_t* __restrict__ run_ctr) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRI ? RT_WALK3_WAVES_TRI : RT_WALK3_WAVES))) void wf_walk_blocks(const WfParams wk, uint32_t* __restrict__ run_ctr) {
     WfParams w = wk;
     if (!resolve_round(w)) return;
     const uint32_t n_queue = w.n_prev_closest;
