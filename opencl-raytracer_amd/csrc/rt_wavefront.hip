@@ -1107,6 +1107,19 @@ __device__ __forceinline__ uint32_t lattice_pretest(uint32_t pm, uint32_t word, 
 #endif
 }
 
+// all candidates of one block (entries last to first, so that bit e of the result is entry e)
+__device__ __forceinline__ uint32_t block_pretests(const uint4 q0, const uint4 q1, float olx, float oly, float olz, float dx, float dy, float dz,
+                                                   float neg_dd, float one_minus_alpha) {
+    uint32_t pm = 0u;
+    if constexpr (kBlockEntries > 6) pm = lattice_pretest(pm, q1.w, olx, oly, olz, dx, dy, dz, neg_dd, one_minus_alpha);
+    if constexpr (kBlockEntries > 5) pm = lattice_pretest(pm, q1.z, olx, oly, olz, dx, dy, dz, neg_dd, one_minus_alpha);
+    if constexpr (kBlockEntries > 4) pm = lattice_pretest(pm, q1.y, olx, oly, olz, dx, dy, dz, neg_dd, one_minus_alpha);
+    if constexpr (kBlockEntries > 3) pm = lattice_pretest(pm, q1.x, olx, oly, olz, dx, dy, dz, neg_dd, one_minus_alpha);
+    if constexpr (kBlockEntries > 2) pm = lattice_pretest(pm, q0.w, olx, oly, olz, dx, dy, dz, neg_dd, one_minus_alpha);
+    if constexpr (kBlockEntries > 1) pm = lattice_pretest(pm, q0.z, olx, oly, olz, dx, dy, dz, neg_dd, one_minus_alpha);
+    return lattice_pretest(pm, q0.y, olx, oly, olz, dx, dy, dz, neg_dd, one_minus_alpha);
+}
+
 template <bool FUSED, bool STATS, bool TRI>
 __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue,
                                               uint32_t wave, uint32_t n_waves, uint32_t* __restrict__ run_ctr,
@@ -1210,15 +1223,8 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
             const float olx = __builtin_fmaf(rsx - __builtin_fmaf(fx, bg.cell, bg.c0x), inv, 128.0f);
             const float oly = __builtin_fmaf(rsy - __builtin_fmaf(fy, bg.cell, bg.c0y), inv, 128.0f);
             const float olz = __builtin_fmaf(rsz - __builtin_fmaf(fz, bg.cell, bg.c0z), inv, 128.0f);
-            uint32_t pm = 0u;  // candidates that pass the pre-test: bit e = entry e (fed last to first)
-            const float neg_dd = -dd, oma = 1.0f - g.pretest_alpha;
-            if constexpr (kBlockEntries > 6) pm = lattice_pretest(pm, q1.w, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
-            if constexpr (kBlockEntries > 5) pm = lattice_pretest(pm, q1.z, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
-            if constexpr (kBlockEntries > 4) pm = lattice_pretest(pm, q1.y, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
-            if constexpr (kBlockEntries > 3) pm = lattice_pretest(pm, q1.x, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
-            if constexpr (kBlockEntries > 2) pm = lattice_pretest(pm, q0.w, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
-            if constexpr (kBlockEntries > 1) pm = lattice_pretest(pm, q0.z, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
-            pm = lattice_pretest(pm, q0.y, olx, oly, olz, rdx, rdy, rdz, neg_dd, oma);
+            // candidates that pass the pre-test: bit e = entry e
+            uint32_t pm = block_pretests(q0, q1, olx, oly, olz, rdx, rdy, rdz, -dd, 1.0f - g.pretest_alpha);
             pm &= 0x7fu << pos;  // (a block the lane comes back to: the entries before `pos` have been dealt with)
             uint32_t back = 0u;
             while (pm != 0u) {  // few lanes, seldom more than once: the ids of the candidates that passed
@@ -1339,14 +1345,7 @@ __device__ __forceinline__ bool closest_hit_blocks(const BlockGrid& bg, const Gr
         const float olx = __builtin_fmaf(ray.sx - __builtin_fmaf(fx, bg.cell, bg.c0x), inv, 128.0f);
         const float oly = __builtin_fmaf(ray.sy - __builtin_fmaf(fy, bg.cell, bg.c0y), inv, 128.0f);
         const float olz = __builtin_fmaf(ray.sz - __builtin_fmaf(fz, bg.cell, bg.c0z), inv, 128.0f);
-        uint32_t pm = 0u;
-        if constexpr (kBlockEntries > 6) pm = lattice_pretest(pm, q1.w, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
-        if constexpr (kBlockEntries > 5) pm = lattice_pretest(pm, q1.z, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
-        if constexpr (kBlockEntries > 4) pm = lattice_pretest(pm, q1.y, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
-        if constexpr (kBlockEntries > 3) pm = lattice_pretest(pm, q1.x, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
-        if constexpr (kBlockEntries > 2) pm = lattice_pretest(pm, q0.w, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
-        if constexpr (kBlockEntries > 1) pm = lattice_pretest(pm, q0.z, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
-        pm = lattice_pretest(pm, q0.y, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        uint32_t pm = block_pretests(q0, q1, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
         while (pm != 0u) {
             const uint32_t k = table_at(bg.ids, 8u * b + (uint32_t)__builtin_ctz(pm));
             pm &= pm - 1u;
@@ -1402,14 +1401,7 @@ __device__ __forceinline__ bool any_hit_blocks(const BlockGrid& bg, const GridDe
         const float olx = __builtin_fmaf(ray.sx - __builtin_fmaf(fx, bg.cell, bg.c0x), inv, 128.0f);
         const float oly = __builtin_fmaf(ray.sy - __builtin_fmaf(fy, bg.cell, bg.c0y), inv, 128.0f);
         const float olz = __builtin_fmaf(ray.sz - __builtin_fmaf(fz, bg.cell, bg.c0z), inv, 128.0f);
-        uint32_t pm = 0u;
-        if constexpr (kBlockEntries > 6) pm = lattice_pretest(pm, q1.w, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
-        if constexpr (kBlockEntries > 5) pm = lattice_pretest(pm, q1.z, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
-        if constexpr (kBlockEntries > 4) pm = lattice_pretest(pm, q1.y, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
-        if constexpr (kBlockEntries > 3) pm = lattice_pretest(pm, q1.x, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
-        if constexpr (kBlockEntries > 2) pm = lattice_pretest(pm, q0.w, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
-        if constexpr (kBlockEntries > 1) pm = lattice_pretest(pm, q0.z, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
-        pm = lattice_pretest(pm, q0.y, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
+        uint32_t pm = block_pretests(q0, q1, olx, oly, olz, ray.dx, ray.dy, ray.dz, neg_dd, oma);
         while (pm != 0u) {
             const uint32_t k = table_at(bg.ids, 8u * b + (uint32_t)__builtin_ctz(pm));
             pm &= pm - 1u;
