@@ -51,6 +51,7 @@ struct rt_context {
     uint32_t n_pairs = 0;
     rt::HotObject* d_hot = nullptr;
     rt::ColdObject* d_cold = nullptr;
+    rt::ObjectRecord* d_objrec = nullptr;   // what materialise() reads of an object, in one 128-byte line
     float4* d_bounds = nullptr;            // screen rectangles for the current camera
     std::vector<double> h_spheres;         // per object: bounding sphere cx, cy, cz, R (R = +inf never cull, -inf never hit)
     bool rects_dirty = true;
@@ -496,6 +497,7 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     p.scene.hot = c->d_hot;
     p.scene.bounds = c->d_bounds;
     p.scene.cold = c->d_cold;
+    p.scene.objrec = c->d_objrec;
     p.scene.lights = c->d_lights;
     p.scene.n_objs = c->n_objs;
     p.scene.n_lights = c->n_lights;
@@ -1620,6 +1622,20 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
             RT_TRY(hipMemcpy(c->d_hot, hot.data(), sizeof(rt::HotObject) * (size_t)(n_objs + 1), hipMemcpyHostToDevice));
         }
         if (n_objs) RT_TRY(hipMemcpy(c->d_cold, cold.data(), sizeof(rt::ColdObject) * n_objs, hipMemcpyHostToDevice));
+        {   // matrix rows of both directions + absorption side by side (ObjectRecord)
+            std::vector<rt::ObjectRecord> rec((size_t)n_objs + 1);
+            std::memset(rec.data(), 0, sizeof(rt::ObjectRecord) * rec.size());
+            for (uint32_t i = 0; i < n_objs; ++i) {
+                rec[i].inv_row[0] = hot[i].row0; rec[i].inv_row[1] = hot[i].row1; rec[i].inv_row[2] = hot[i].row2;
+                rec[i].type = hot[i].type;
+                rec[i].pad0 = hot[i].pad[0];
+                rec[i].absorption = cold[i].amb_absorb.w;
+                for (int r = 0; r < 3; ++r) rec[i].mv_row[r] = cold[i].mv_row[r];
+            }
+            rec[n_objs].type = 0xffffffffu;
+            RT_TRY(hipMalloc((void**)&c->d_objrec, sizeof(rt::ObjectRecord) * rec.size()));
+            RT_TRY(hipMemcpy(c->d_objrec, rec.data(), sizeof(rt::ObjectRecord) * rec.size(), hipMemcpyHostToDevice));
+        }
     }
     RT_TRY(hipMalloc((void**)&c->d_lights, sizeof(rt::LightRec) * (size_t)(n_lights + 1)));
     if (n_lights) RT_TRY(hipMemcpy(c->d_lights, lights, sizeof(rt::LightRec) * n_lights, hipMemcpyHostToDevice));
@@ -1862,6 +1878,7 @@ void rt_destroy(rt_context* c) {
     if (c->d_shadow_pairs) (void)hipFree(c->d_shadow_pairs);
     if (c->d_hot) (void)hipFree(c->d_hot);
     if (c->d_cold) (void)hipFree(c->d_cold);
+    if (c->d_objrec) (void)hipFree(c->d_objrec);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
     if (c->d_grid_cell_range) (void)hipFree(c->d_grid_cell_range);
     if (c->d_grid_cell_rec) (void)hipFree(c->d_grid_cell_rec);

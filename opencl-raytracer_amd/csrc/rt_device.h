@@ -48,10 +48,22 @@ struct ColdObject {  // 128 B
     float4 dif_shine;    // diffuse rgb, shininess
     float4 spec_type;    // specular rgb, type bits
 };
+// What materialise() needs of an object, in ONE 128-byte line (round 3): rows x,y,z of mvInverse (= the HotObject, which stays
+// the walks' 64-byte record), rows x,y,z of mv, and the absorption the loop bookkeeping reads right after. wf_resume was gathering
+// these from two records in two lines - by section 4.4's figures a line fill is ~5 CU-cycles of a pixel-step that has ~45.
+struct ObjectRecord {
+    float4 inv_row[3];   // as HotObject::row0..2 (triangles: (v0, cx), (e1, cy), (e2, cz))
+    uint32_t type;
+    uint32_t pad0;       // triangles: bits of the guard radius (HotObject::pad[0])
+    float absorption;    // mat.absorption (ColdObject::amb_absorb.w)
+    uint32_t spare0;
+    float4 mv_row[3];    // as ColdObject::mv_row[0..2]
+    float4 spare1;
+};
 struct LightRec {    // the reference's 64-byte Light, unchanged
     float4 ambient, diffuse, specular, position;
 };
-static_assert(sizeof(HotObject) == 64 && sizeof(ColdObject) == 128 && sizeof(LightRec) == 64, "layout");
+static_assert(sizeof(HotObject) == 64 && sizeof(ColdObject) == 128 && sizeof(LightRec) == 64 && sizeof(ObjectRecord) == 128, "layout");
 
 // Read-only scene data is addressed through the constant address space: that tells the compiler the bytes
 // cannot change during the kernel, so a wave-uniform address becomes a scalar load (s_load_dwordx4/8/16) even
@@ -532,14 +544,16 @@ struct ObjRows {
 };
 
 template <bool FUSED>
-__device__ __forceinline__ void materialise(const HotObject* __restrict__ hot, const ColdObject* __restrict__ cold,
-                                            int index, float t, const Ray& ray, HitRec& h, bool affine = false, ObjRows* rows = nullptr) {
-    const HotObject* o = hot + index;
-    const ColdObject* c = cold + index;
+__device__ __forceinline__ void materialise(const ObjectRecord* __restrict__ objrec, const ColdObject* __restrict__ cold,
+                                            int index, float t, const Ray& ray, HitRec& h, bool affine = false, ObjRows* rows = nullptr,
+                                            float* absorption = nullptr) {
+    const ObjectRecord* o = objrec + index;
+    const ColdObject* c = cold + index;   // (only touched for the bottom rows of a non-affine instance)
     const uint32_t type = o->type;
-    if (rows) { rows->r0 = o->row0; rows->r1 = o->row1; rows->r2 = o->row2; rows->type = type; rows->pad0 = o->pad[0]; }
+    if (rows) { rows->r0 = o->inv_row[0]; rows->r1 = o->inv_row[1]; rows->r2 = o->inv_row[2]; rows->type = type; rows->pad0 = o->pad0; }
+    if (absorption) *absorption = o->absorption;
     if (type == 2u) {  // triangle (extension): view-space point on the ray, normal = normalize(e1 x e2)
-        const float4 e1 = o->row1, e2 = o->row2;
+        const float4 e1 = o->inv_row[1], e2 = o->inv_row[2];
         h.px = fma_<FUSED>(t, ray.dx, ray.sx);
         h.py = fma_<FUSED>(t, ray.dy, ray.sy);
         h.pz = fma_<FUSED>(t, ray.dz, ray.sz);
@@ -556,7 +570,7 @@ __device__ __forceinline__ void materialise(const HotObject* __restrict__ hot, c
         h.index = index;
         return;
     }
-    const float4 r0 = o->row0, r1 = o->row1, r2 = o->row2;
+    const float4 r0 = o->inv_row[0], r1 = o->inv_row[1], r2 = o->inv_row[2];
     const float sx = row4<FUSED>(r0.x, r0.y, r0.z, r0.w, ray.sx, ray.sy, ray.sz, ray.sw);
     const float sy = row4<FUSED>(r1.x, r1.y, r1.z, r1.w, ray.sx, ray.sy, ray.sz, ray.sw);
     const float sz = row4<FUSED>(r2.x, r2.y, r2.z, r2.w, ray.sx, ray.sy, ray.sz, ray.sw);
@@ -588,7 +602,7 @@ __device__ __forceinline__ void materialise(const HotObject* __restrict__ hot, c
         if (py > 0.4998f) oy += 1.f; else if (py < -0.4998f) oy -= 1.f;
         if (pz > 0.4998f) oz += 1.f; else if (pz < -0.4998f) oz -= 1.f;
     }
-    const float4 m0 = c->mv_row[0], m1 = c->mv_row[1], m2 = c->mv_row[2];
+    const float4 m0 = o->mv_row[0], m1 = o->mv_row[1], m2 = o->mv_row[2];
     h.px = row4<FUSED>(m0.x, m0.y, m0.z, m0.w, px, py, pz, pw);
     h.py = row4<FUSED>(m1.x, m1.y, m1.z, m1.w, px, py, pz, pw);
     h.pz = row4<FUSED>(m2.x, m2.y, m2.z, m2.w, px, py, pz, pw);
@@ -645,6 +659,7 @@ struct Scene {
     const float4* __restrict__ bounds;   // per object (pinhole grids, <= 64 objects): conservative screen rectangle
                                          // (xmin, xmax, ymin, ymax) in ray-direction units; empty = can never be hit
     const ColdObject* __restrict__ cold;
+    const ObjectRecord* __restrict__ objrec;  // per object: what materialise() reads, in one line
     const LightRec* __restrict__ lights;
     uint32_t n_objs;
     uint32_t n_lights;
@@ -870,7 +885,7 @@ __device__ __forceinline__ void shade_and_reflect_pixel(const Scene& S, uint32_t
         if (T == kMaxFloat) break;  // raycast() returned false (:173)
         if (!absorbing) break;
         HitRec rh;
-        materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh, S.affine != 0u);
+        materialise<FUSED>(S.objrec, S.cold, idx, T, ray, rh, S.affine != 0u);
         shade_assign<FUSED, COUNT>(S, rh, rr, rg, rb, ctr);
         const float ra = (1.f - ap) * S.cold[rh.index].amb_absorb.w;
         abr = fma_<FUSED>(ra, rr, abr); abg = fma_<FUSED>(ra, rg, abg); abb = fma_<FUSED>(ra, rb, abb);

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void render_pixels(const RenderParams p) {
             if constexpr (KERNEL != 0) {
                 if (hit) {
                     HitRec h;
-                    materialise<FUSED>(S.hot, S.cold, idx, T, ray, h, S.affine != 0u);
+                    materialise<FUSED>(S.objrec, S.cold, idx, T, ray, h, S.affine != 0u);
                     if constexpr (KERNEL == 1) shade_forward<FUSED, true, COUNT>(S, h, outr, outg, outb, ctr);
                     else shade_and_reflect_pixel<FUSED, COUNT>(S, p.max_bounces, h, outr, outg, outb, ctr);
                 }

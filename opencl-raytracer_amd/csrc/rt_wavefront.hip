@@ -1896,13 +1896,14 @@ __device__ __forceinline__ void loop_step(Ctx& c, const HitRec& from, float abr,
         ray.dw = 0.0f;  // (a reflection ray's direction.w; the slot may carry begin_shade_lit's note to the walk)
         HitRec rh;
         ObjRows rows;
-        materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh, S.affine != 0u, &rows);
+        float absorb_rh;
+        materialise<FUSED>(S.objrec, S.cold, idx, T, ray, rh, S.affine != 0u, &rows, &absorb_rh);
         store_loop_state(c, abr, abg, abb, rr, rg, rb, ap, bounces, false);
         if (c.pre) {  // the step may go on to shade rh on the spot (shade_last_light_inline): what it preloaded is now this
             c.pre_acc = make_float4(abr, abg, abb, ap);
             c.pre_res.w = __uint_as_float(bounces);
         }
-        const float ra = (1.f - ap) * S.cold[rh.index].amb_absorb.w;  // shade_done's update, ahead of time
+        const float ra = (1.f - ap) * absorb_rh;  // shade_done's update, ahead of time (the absorption came with the record)
         begin_shade_lit<2, FUSED>(c, rh, false, bounces, ap + ra, rows);
         return;
     }
@@ -1965,8 +1966,9 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
             const Ray ray = closest_ray(w, i, true);
             HitRec h;
             ObjRows rows;
-            materialise<FUSED>(S.hot, S.cold, idx, T, ray, h, S.affine != 0u, &rows);
-            begin_shade<KERNEL, FUSED>(c, h, true, w.rp.max_bounces, S.cold[h.index].amb_absorb.w, rows);
+            float absorb_h;
+            materialise<FUSED>(S.objrec, S.cold, idx, T, ray, h, S.affine != 0u, &rows, &absorb_h);
+            begin_shade<KERNEL, FUSED>(c, h, true, w.rp.max_bounces, absorb_h, rows);
         }
     } else if (phase == PH_SHADOW_PRIMARY || phase == PH_SHADOW_REFLECT) {
         c.pre = true;
@@ -1991,8 +1993,9 @@ __device__ __forceinline__ void resume_pixel(Ctx& c) {
             ray.dw = 0.0f;  // (a reflection ray's direction.w; the slot may carry begin_shade_lit's note to the walk)
             HitRec rh;
             ObjRows rows;
-            materialise<FUSED>(S.hot, S.cold, idx, T, ray, rh, S.affine != 0u, &rows);
-            begin_shade<KERNEL, FUSED>(c, rh, false, bounces, ap + (1.f - ap) * S.cold[rh.index].amb_absorb.w, rows);
+            float absorb_rh;
+            materialise<FUSED>(S.objrec, S.cold, idx, T, ray, rh, S.affine != 0u, &rows, &absorb_rh);
+            begin_shade<KERNEL, FUSED>(c, rh, false, bounces, ap + (1.f - ap) * absorb_rh, rows);
         }
     }
 }
