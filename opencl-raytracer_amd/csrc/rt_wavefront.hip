@@ -20,6 +20,7 @@
 #include "rt_grid.h"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -2343,13 +2344,16 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
         }
         if ((e = hipMemcpyAsync(buf.h_counts, rs, RS_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, stream)) != hipSuccess) return e;
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        if (std::getenv("RT_ROUND_STATS"))  // engineering aid (with RT_WF_BATCH=1: after every round)
+            std::fprintf(stderr, "[rounds] after %u round(s): closest queue %u, shadow queue %u, hand-over %u\n", buf.h_counts[RS_ROUNDS],
+                         buf.h_counts[RS_N_CLOSEST], buf.h_counts[RS_N_ANY], buf.h_counts[RS_FINISH]);
         if (buf.h_counts[RS_FINISH] != 0u) break;  // 2: the queues ran empty; 1: wf_finish (enqueued above) took the rest
         if (nc_max + na_max == 0) break;
         // still going (long light scans, deep bounce chains): what is alive bounds every later queue
         const uint64_t alive = (uint64_t)buf.h_counts[RS_N_CLOSEST] + buf.h_counts[RS_N_ANY];
         nc_max = std::min<uint64_t>(n, alive);
         na_max = std::min<uint64_t>(n, alive);
-        batch = 8;
+        batch = std::getenv("RT_ROUND_STATS") ? 1u : 8u;
     }
     if (rounds_out) *rounds_out = buf.h_counts[RS_ROUNDS];
     return hipSuccess;
