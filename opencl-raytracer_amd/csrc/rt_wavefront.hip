@@ -606,6 +606,9 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             const LightTiles& lt = w.ltiles;
             const uint32_t b = e & 0xffffffu, pos = e >> 24;
             const uint4 q0 = table_at(lt.blocks, 2u * b), q1 = table_at(lt.blocks, 2u * b + 1u);
+            // (the block's ids are requested WITH the block, not after its pre-tests: 0.8 of a shadow ray's 1.1 blocks have a
+            // candidate that passes, and the walk is a chain of dependent fetches - 16 bytes more per block, one step less per ray)
+            const uint4 kk = table_at(reinterpret_cast<const uint4*>(lt.block_ids), b);
             const uint32_t nxt = q0.x;
             const uint32_t lo[3] = {q0.z, q1.x, q1.z}, hi[3] = {q0.w, q1.y, q1.w};
             uint32_t pm = 0u;
@@ -624,7 +627,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             uint32_t stalled = 0u, back = 0u, parked = pend ? 1u : 0u;
             while (pm != 0u) {  // the ids of the candidates that passed
                 const uint32_t j = (uint32_t)__builtin_ctz(pm);
-                const uint32_t k = table_at(lt.block_ids, 4u * b + j);
+                const uint32_t k = j == 0u ? kk.x : (j == 1u ? kk.y : kk.z);
                 const bool dup = (k == done_k) || (parked != 0u && k == pend_k);
                 const bool wait = !dup && parked != 0u;   // one parking slot: wait for the exact tests, resume at this entry
                 const bool take = !dup && parked == 0u;
@@ -952,6 +955,9 @@ __device__ __forceinline__ void walk_segment(const WfParams& w, const uint32_t* 
             const LightTiles& lt = w.ltiles;
             const uint32_t b = cursor & 0xffffffu, pos = cursor >> 24;
             const uint4 q0 = table_at(lt.blocks, 2u * b), q1 = table_at(lt.blocks, 2u * b + 1u);
+            // (the block's ids are requested WITH the block, not after its pre-tests: 0.8 of a shadow ray's 1.1 blocks have a
+            // candidate that passes, and the walk is a chain of dependent fetches - 16 bytes more per block, one step less per ray)
+            const uint4 kk = table_at(reinterpret_cast<const uint4*>(lt.block_ids), b);
             const uint32_t nxt = q0.x;
             const uint32_t lo[3] = {q0.z, q1.x, q1.z}, hi[3] = {q0.w, q1.y, q1.w};
             uint32_t pm = 0u;
@@ -969,7 +975,7 @@ __device__ __forceinline__ void walk_segment(const WfParams& w, const uint32_t* 
             uint32_t stalled = 0u, back = 0u, parked = pend ? 1u : 0u;
             while (pm != 0u) {  // the ids of the candidates that passed
                 const uint32_t e = (uint32_t)__builtin_ctz(pm);
-                const uint32_t k = table_at(lt.block_ids, 4u * b + e);
+                const uint32_t k = e == 0u ? kk.x : (e == 1u ? kk.y : kk.z);
                 const bool dup = (k == done_k) || (parked != 0u && k == pend_k);
                 const bool wait = !dup && parked != 0u;   // one parking slot: wait for the exact tests, resume at this entry
                 const bool take = !dup && parked == 0u;
@@ -1076,6 +1082,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK2_WA
 #ifndef RT_WALK3_WAVES
 #define RT_WALK3_WAVES 6
 #endif
+#ifndef RT_WALK3_REFILL_MIN
+#define RT_WALK3_REFILL_MIN RT_WALK2_REFILL_MIN
+#endif
+#ifndef RT_WALK3_DEFER_PENDING
+#define RT_WALK3_DEFER_PENDING 16  // exact tests of the block walk once this many lanes hold a candidate (a trip is ~300 instructions here, the
+#endif                             // test ~150): cfg4 frame with 8 / 12 / 16 / 24: 12.07 / 11.93 / 11.99 / 12.06 ms, 16 with half the lanes stuck: 11.92
+#ifndef RT_WALK3_STUCK_SHIFT
+#define RT_WALK3_STUCK_SHIFT 1     // ... or once HALF of the live lanes cannot move without theirs (walk_segment: a quarter)
+#endif
 #ifndef RT_BLOCK_SKIP_CAP
 #define RT_BLOCK_SKIP_CAP 8   // empty-space steps a lane takes per trip beyond the first (the other lanes of the wave wait for it)
 #endif
@@ -1158,7 +1173,7 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
     for (;;) {
         // ---- hand out rays to idle lanes ----
         const unsigned long long idle = __ballot((fl & kAlive) == 0u);
-        if (next < seg_end && ((uint32_t)__popcll(idle) >= (uint32_t)RT_WALK2_REFILL_MIN || idle == ~0ull)) {
+        if (next < seg_end && ((uint32_t)__popcll(idle) >= (uint32_t)RT_WALK3_REFILL_MIN || idle == ~0ull)) {
             const uint32_t mine = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             if (STATS && lane == 0u) ++s_refill;
             if ((fl & kAlive) == 0u && mine < seg_end) {
@@ -1284,8 +1299,8 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
         if (pending != 0ull) {
             const unsigned long long stuck = __ballot((fl & kPend) != 0u && (stalled != 0u || (fl & kOver) != 0u));
             const uint32_t n_live = (uint32_t)__popcll(live);
-            if ((uint32_t)__popcll(pending) >= (uint32_t)RT_WALK2_DEFER_PENDING ||
-                ((uint32_t)__popcll(stuck) << RT_DEFER_STUCK_SHIFT) >= n_live) {
+            if ((uint32_t)__popcll(pending) >= (uint32_t)RT_WALK3_DEFER_PENDING ||
+                ((uint32_t)__popcll(stuck) << RT_WALK3_STUCK_SHIFT) >= n_live) {
                 if (STATS && lane == 0u) ++s_flush;
                 if ((fl & kPend) != 0u) {
                     float t;
@@ -1600,7 +1615,8 @@ __device__ __forceinline__ bool last_light_blocked(const WfParams& w, Ray ray, u
         const float dd = ray.dx * ray.dx + ray.dy * ray.dy + ray.dz * ray.dz;
         for (uint32_t b = tile;;) {
             const uint4 q0 = table_at(lt.blocks, 2u * b), q1 = table_at(lt.blocks, 2u * b + 1u);
-            const uint32_t lo[3] = {q0.z, q1.x, q1.z}, hi[3] = {q0.w, q1.y, q1.w};
+            const uint4 kk = table_at(reinterpret_cast<const uint4*>(lt.block_ids), b);  // (with the block, not after its pre-tests: walk_segment)
+            const uint32_t lo[3] = {q0.z, q1.x, q1.z}, hi[3] = {q0.w, q1.y, q1.w}, ids[3] = {kk.x, kk.y, kk.z};
 #pragma unroll
             for (uint32_t e = 0; e < 3u; ++e) {
                 float4 sphere;
@@ -1611,7 +1627,7 @@ __device__ __forceinline__ bool last_light_blocked(const WfParams& w, Ray ray, u
                 float t;
                 bool sphere_type;
                 ++tests;
-                if (lane_candidate<FUSED, true, true>(hot + table_at(lt.block_ids, 4u * b + e), ray, t, sphere_type) && !(t >= 1.f)) return true;
+                if (lane_candidate<FUSED, true, true>(hot + ids[e], ray, t, sphere_type) && !(t >= 1.f)) return true;
             }
             if (q0.x == 0u) return false;
             b = q0.x;
