@@ -1091,6 +1091,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK2_WA
 #ifndef RT_WALK3_STUCK_SHIFT
 #define RT_WALK3_STUCK_SHIFT 1     // ... or once HALF of the live lanes cannot move without theirs (walk_segment: a quarter)
 #endif
+#ifndef RT_WALK3_DEFER_PENDING_TRI
+#define RT_WALK3_DEFER_PENDING_TRI RT_WALK2_DEFER_PENDING  // meshes keep the earlier pair (8, a quarter): cfg5 38.97 ms against 40.15 with 16 / half
+#endif
+#ifndef RT_WALK3_STUCK_SHIFT_TRI
+#define RT_WALK3_STUCK_SHIFT_TRI RT_DEFER_STUCK_SHIFT
+#endif
 #ifndef RT_BLOCK_SKIP_CAP
 #define RT_BLOCK_SKIP_CAP 8   // empty-space steps a lane takes per trip beyond the first (the other lanes of the wave wait for it)
 #endif
@@ -1299,8 +1305,8 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
         if (pending != 0ull) {
             const unsigned long long stuck = __ballot((fl & kPend) != 0u && (stalled != 0u || (fl & kOver) != 0u));
             const uint32_t n_live = (uint32_t)__popcll(live);
-            if ((uint32_t)__popcll(pending) >= (uint32_t)RT_WALK3_DEFER_PENDING ||
-                ((uint32_t)__popcll(stuck) << RT_WALK3_STUCK_SHIFT) >= n_live) {
+            if ((uint32_t)__popcll(pending) >= (uint32_t)(TRI ? RT_WALK3_DEFER_PENDING_TRI : RT_WALK3_DEFER_PENDING) ||
+                ((uint32_t)__popcll(stuck) << (TRI ? RT_WALK3_STUCK_SHIFT_TRI : RT_WALK3_STUCK_SHIFT)) >= n_live) {
                 if (STATS && lane == 0u) ++s_flush;
                 if ((fl & kPend) != 0u) {
                     float t;
