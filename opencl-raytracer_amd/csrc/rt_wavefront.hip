@@ -1097,6 +1097,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK2_WA
 #ifndef RT_WALK3_STUCK_SHIFT_TRI
 #define RT_WALK3_STUCK_SHIFT_TRI RT_DEFER_STUCK_SHIFT
 #endif
+#ifndef RT_STATS_TAIL
+#define RT_STATS_TAIL 0
+#endif
 #ifndef RT_BLOCK_SKIP_CAP
 #define RT_BLOCK_SKIP_CAP 8   // empty-space steps a lane takes per trip beyond the first (the other lanes of the wave wait for it)
 #endif
@@ -1159,6 +1162,7 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
     const float wnx_f = (float)bg.wnx, wny_f = (float)bg.wny;
 
     unsigned long long s_rays = 0, s_trips = 0, s_live = 0, s_fetch = 0, s_pre = 0, s_flush = 0, s_refill = 0;  // STATS only
+    unsigned long long t_dry = 0, s_sum_after = 0; uint32_t my_trips = 0, max_trips = 0, trips_after = 0;  // STATS + RT_STATS_TAIL
     // The lane's state bits live in ONE vector register and are changed with vector and / or: as `bool`s carried round
     // the loop the compiler keeps them as 64-bit lane masks in scalar registers, and every merge of divergent paths costs
     // an andn2 / and / or triple per flag (round 2's walk: 0.75 scalar instructions per vector instruction).
@@ -1183,7 +1187,7 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
             const uint32_t mine = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
             if (STATS && lane == 0u) ++s_refill;
             if ((fl & kAlive) == 0u && mine < seg_end) {
-                if (STATS) ++s_rays;
+                if (STATS) { ++s_rays; my_trips = 0; }
                 const uint32_t entry = w.identity_queue ? mine : queue[mine];
                 pix = w.identity_queue ? mine : (entry & kQueuePixel);
                 Ray ray = closest_ray(w, pix, w.first_round != 0u);
@@ -1234,7 +1238,7 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
         // ---- one trip: the block under the cursor ----
         const bool walking = (fl & (kAlive | kOver)) == kAlive;
         uint32_t stalled = 0u;
-        if (STATS) { if (lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); } if (walking) { s_pre += kBlockEntries; if ((cur & 0xffffffu) < bg.n_cells) ++s_fetch; } }
+        if (STATS) { if (lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); } if (walking) { s_pre += kBlockEntries; ++my_trips; max_trips = my_trips > max_trips ? my_trips : max_trips; if ((cur & 0xffffffu) < bg.n_cells) ++s_fetch; } if (RT_STATS_TAIL && t_dry == 0 && next >= seg_end && !more) t_dry = wall_clock64(); if (t_dry != 0) ++trips_after; }
         if (walking) {
             const uint32_t b = cur & 0xffffffu, pos = cur >> 24;
             const uint4 q0 = table_at(bg.blocks, 2u * b);
@@ -1332,7 +1336,16 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
     }
     if (STATS) {
         unsigned long long* acc = w.rp.counters->walk[0];
+#if RT_STATS_TAIL  // (engineering build: the last two columns become the longest end-game of a wave - 10 ns ticks between its queue running dry and its exit - in the low 32 bits + its trips in that time in the high ones; and the longest ray in trips)
+        const unsigned long long after = t_dry ? wall_clock64() - t_dry : 0ull;
+        if (lane == 0u) { atomicMax(&acc[6], (after << 32) | (unsigned long long)trips_after); }
+        uint32_t mt = max_trips;
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)mt, o); mt = other > mt ? other : mt; }
+        if (lane == 0u) atomicMax(&acc[7], (unsigned long long)mt);
+        const unsigned long long v[8] = {wave_sum64(s_rays), s_trips, s_live, wave_sum64(s_fetch), wave_sum64(s_pre), wave_sum64(tested), 0ull, 0ull};
+#else
         const unsigned long long v[8] = {wave_sum64(s_rays), s_trips, s_live, wave_sum64(s_fetch), wave_sum64(s_pre), wave_sum64(tested), s_flush, s_refill};
+#endif
         if (lane == 0u)
             for (int j = 0; j < 8; ++j)
                 if (v[j]) atomicAdd(&acc[j], v[j]);
