@@ -155,7 +155,7 @@ def cpu_backend_baseline(objs, lights, rays, kernel, depth, sample_desc):
             "what": "CPURaytracer : IRaytracer (host/CPURaytracer.cpp), every ray against every object like the reference's kernels"}
 
 
-def measure_brute_force_window(device_index, edge):
+def measure_brute_force_window(device_index, edge, default_frame=None):
     """The brute-force traversal (every object for every ray: packed-pair stream, RT_FLAG_NO_GRID) on the centred
     edge x edge window of the cfg4 grid - the kernel that is measured against the FP32 VALU roofline."""
     import torch
@@ -189,6 +189,13 @@ def measure_brute_force_window(device_index, edge):
            "bound": "valu", "achieved": valu / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "roofline_unit": "T lane-instr/s",
            "frac": valu / VALU_PEAK_LANE_OPS, "object_tests": int(st.object_tests),
            "tests_per_s": st.object_tests / (kernel_ms * 1e-3)}
+    if default_frame is not None and edge >= W and tuple(default_frame.shape) == tuple(out.shape):
+        # the same frame by two routes - every object tested for every ray here, screen tiles + block walk + light tiles in the timed
+        # run: all 4 x 16.8 M words must agree bit for bit (the grid is an exact elimination)
+        same = torch.eq(out.view(torch.int32), default_frame.view(torch.int32))
+        res["frame_bit_identical_to_default_path"] = bool(same.all().item())
+        res["pixels_compared"] = int(out.shape[0])
+        res["pixels_differing"] = int((~same.all(dim=1)).sum().item())
     rt.close()
     return res
 
@@ -526,7 +533,7 @@ def main():
                     "kernels the grid replaces - which ARE bound by those tests - are measured in brute_force") % (
                         tests / max(rays_act, 1), len(objs))
                 if world == 1 and not args.no_extra:
-                    out["roofline"]["brute_force"] = measure_brute_force_window(local_rank, 4096)
+                    out["roofline"]["brute_force"] = measure_brute_force_window(local_rank, 4096, default_frame=frame if torch.is_tensor(frame) else None)
         elif args.workload == "cfg5":
             hbm["kernel"] = "rt::wf_trace_grid_persistent<closest|any, triangles> + rt::wf_trace_primary_tiles (+ wf_resume)"
             hbm["note"] = ("triangles are this repo's extension (no reference semantics; SURVEY.md 8f5 defines no per-test work "
