@@ -1104,9 +1104,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WALK2_WA
 #define RT_BLOCK_SKIP_CAP 8   // empty-space steps a lane takes per trip beyond the first (the other lanes of the wave wait for it)
 #endif
 
-#ifndef RT_PRETEST_SIGN_BITS
-#define RT_PRETEST_SIGN_BITS 1
-#endif
 #ifndef RT_LATTICE_BEHIND
 #define RT_LATTICE_BEHIND 0  // 1: also reject spheres entirely behind the origin (3 more instructions per candidate, ~15 % fewer exact tests: cfg4 +0.33 ms)
 #endif
@@ -1131,13 +1128,7 @@ __device__ __forceinline__ uint32_t lattice_pretest(uint32_t pm, uint32_t word, 
     const float s = __builtin_fmaxf(-disc, __builtin_fminf(-od, behind));
     return pm + pm + (s > 0.f ? 0u : 1u);
 #else
-#if RT_PRETEST_SIGN_BITS
-    // (the verdict is disc's sign bit - no -0 can arise: od od >= +0 and the fused sum rounds to nearest - shifted in with ONE
-    //  instruction, v_alignbit; the caller inverts the seven collected MISS bits: 9 instead of 19 instructions per block)
-    return __builtin_amdgcn_alignbit(pm, __float_as_uint(disc), 31u);
-#else
     return pm + pm + (disc < 0.f ? 0u : 1u);
-#endif
 #endif
 }
 
@@ -1151,11 +1142,7 @@ __device__ __forceinline__ uint32_t block_pretests(const uint4 q0, const uint4 q
     if constexpr (kBlockEntries > 3) pm = lattice_pretest(pm, q1.x, olx, oly, olz, dx, dy, dz, neg_dd, one_minus_alpha);
     if constexpr (kBlockEntries > 2) pm = lattice_pretest(pm, q0.w, olx, oly, olz, dx, dy, dz, neg_dd, one_minus_alpha);
     if constexpr (kBlockEntries > 1) pm = lattice_pretest(pm, q0.z, olx, oly, olz, dx, dy, dz, neg_dd, one_minus_alpha);
-    pm = lattice_pretest(pm, q0.y, olx, oly, olz, dx, dy, dz, neg_dd, one_minus_alpha);
-#if RT_PRETEST_SIGN_BITS && !RT_LATTICE_BEHIND
-    pm = ~pm & ((1u << kBlockEntries) - 1u);
-#endif
-    return pm;
+    return lattice_pretest(pm, q0.y, olx, oly, olz, dx, dy, dz, neg_dd, one_minus_alpha);
 }
 
 template <bool FUSED, bool STATS, bool TRI>
