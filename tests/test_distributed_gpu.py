@@ -33,6 +33,12 @@ def test_ranks_sharing_one_gpu_over_gloo(world):
     _run("gloo", world)
 
 
+def test_one_rank_over_rccl():
+    """RCCL itself on this image and box: process-group set-up bound to the device, barrier, broadcast and the exchange's code
+    path with a single rank (what a one-GPU box can say about the backend the multi-GPU runs use)."""
+    _run("nccl", 1)
+
+
 def test_two_ranks_over_rccl():
     import torch
     if torch.cuda.device_count() < 2:
