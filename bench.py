@@ -13,9 +13,10 @@ shade_and_reflect, depth 3 - it fits one GPU (32 MB of scene) and is the same fr
 values are comparable (strong scaling). At N = 1 the line also carries `extra.cfg3`: BASELINE configs[2]
 (simpleScene 4096x4096 depth 3, the HBM-bound small-scene kernel) with its own HBM roofline.
 
-Prints ONE JSON line (rank 0). `value` is Mrays/s counting the rays the reference semantics trace for the
-frame (primary + shadow + reflection = R_ref, the unit both this backend and the reference are charged for the
-same frame); `rays_traced` is what this backend actually issued after its exact eliminations.
+Prints ONE JSON line (rank 0). `value` is Mrays/s over the rays this backend really TRACED for the frame (primary +
+shadow + reflection after its exact eliminations = R_act, SURVEY.md 8d's primary figure); the rays the reference
+semantics trace for the same frame (R_ref: every shadow ray of every light, 15x more for the default workload) are
+reported beside it as `mrays_reference_equivalent_per_s` - algebra saved, not throughput.
 """
 from __future__ import annotations
 
@@ -185,7 +186,8 @@ def measure_brute_force_window(device_index, edge, default_frame=None):
     res = {"workload": ("same frame" if edge >= W else f"same scene, centred {edge}x{edge} window of the 4096x4096 grid") +
                        ", every object tested for every ray (RT_FLAG_NO_GRID)",
            "kernel": "rt::wf_trace_closest + rt::wf_trace_any_slice (+ wf_resume)",
-           "value": st.rays_reference / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
+           "value": st.rays_traced / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3,
+           "mrays_reference_equivalent_per_s": st.rays_reference / dt / 1e6,
            "bound": "valu", "achieved": valu / 1e12, "peak": VALU_PEAK_LANE_OPS / 1e12, "roofline_unit": "T lane-instr/s",
            "frac": valu / VALU_PEAK_LANE_OPS, "object_tests": int(st.object_tests),
            "tests_per_s": st.object_tests / (kernel_ms * 1e-3)}
@@ -233,7 +235,8 @@ def measure_cfg3(device_index, fast_phong=False):
         roof["traffic_source"] = f"profiles/frame_cfg3.json (rocprofv3 PMC, library {prof['lib_sha16']})"
     else:
         roof["traffic_unavailable"] = why
-    res = {"workload": desc, "value": st.rays_reference / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3, "steps": steps,
+    res = {"workload": desc, "value": st.rays_traced / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt * 1e3, "steps": steps,
+           "mrays_reference_equivalent_per_s": st.rays_reference / dt / 1e6,
            "render_wall_ms_incl_d2h": rt.render_host_ms(3), "setup_ms": rt.setup_times(),
            "rays_reference": int(st.rays_reference), "rays_traced": int(st.rays_traced), "hit_pixels": int(st.hit_pixels),
            "mrays_traced_per_s": st.rays_traced / dt / 1e6, "roofline": roof}
@@ -446,7 +449,7 @@ def main():
     if rank == 0:
         assert frame is not None and frame.shape[0] == n_rays
         ms_per_step = elapsed / steps * 1e3
-        value = rays_ref * steps / elapsed / 1e6
+        value = rays_act * steps / elapsed / 1e6  # rays really traced (R_act); R_ref/t is mrays_reference_equivalent_per_s
         kernel_ms = kernel_ms_sum / max(launches, 1)
         # algorithmic (compulsory) HBM bytes per launch of this rank's kernel:
         #   16 B/ray framebuffer write (+ 32 B/ray ray-buffer read when rays come from HBM) + scene as uploaded
@@ -468,11 +471,11 @@ def main():
                                      + (f" [{pipeline_note}]" if pipeline_note else ""))
                        if world > 1 else "single GPU", "arithmetic": "fused (fma where the OpenCL front-end marks fmuladd)",
                        "literal": bool(args.literal), "fast_phong": bool(args.fast_phong)},
-            # `value` counts the rays the REFERENCE semantics trace for the frame (R_ref); what this backend
-            # actually traced after its exact eliminations is rays_traced / mrays_traced_per_s - quote that one against
-            # other raytracers
+            # `value` counts the rays this backend really traced (R_act: the figure to hold against other
+            # raytracers); the rays the REFERENCE semantics trace for the same frame (R_ref) give the reference-equivalent rate
             "rays_reference": rays_ref, "rays_traced": rays_act, "hit_pixels": hit_pixels,
             "mrays_traced_per_s": rays_act * steps / elapsed / 1e6,
+            "mrays_reference_equivalent_per_s": rays_ref * steps / elapsed / 1e6,
             "library_sha16": library_sha16(),
             "render_wall_ms_incl_d2h": render_wall_ms,
             "setup_ms": setup_ms,

@@ -72,7 +72,14 @@ typedef enum rt_kernel {
                                   early-out, backward light scan, dead reflection ray). Results are identical.
                                   rt_create sets it by itself for a scene with a DEGENERATE instance (non-finite or
                                   singular mvInverse): its NaN hit times make the reference's result depend on the
-                                  order of the object loop, which only the literal loops reproduce               */
+                                  order of the object loop, which only the literal loops reproduce - and for a frame
+                                  whose PRIMARY rays leave the domain of the exact eliminations: any direction with
+                                  |d|^2 == 0, < 1e-30 or > 1e30 (or not finite) in the uploaded buffer, or a pinhole
+                                  camera (rt_set_camera) that produces one. The reference's tests give such a ray a
+                                  NaN time on EVERY object (shade_and_reflect_kernel.cl:85-108). Domain of the default
+                                  (grid) path therefore: finite rays with start.w = 1, direction.w = 0,
+                                  1e-30 < |d|^2 < 1e30, affine instances; everything else is rendered by the
+                                  brute-force or literal loops, never approximated                               */
 #define RT_FLAG_NO_RAYGEN 0x4u /* never replace an uploaded pinhole ray grid by in-kernel generation            */
 #define RT_FLAG_WAVEFRONT  0x8u  /* force the large-scene path (separate traversal / shading kernels)          */
 #define RT_FLAG_NO_GRID    0x20u /* large-scene path: test every object for every ray (no conservative grid culling);
@@ -180,7 +187,9 @@ void rt_destroy(rt_context* ctx);
  * on devices[0] - the gather of SURVEY.md 8e without a second process or a collective library.
  *   rt_render_multi         synchronous, like rt_render: the whole frame (n_rays elements) in a host buffer owned by `m`
  *   rt_render_multi_device  the whole frame into caller-provided memory ON devices[0] (n_rays elements, padded up to whole
- *                           tiles: rt_multi_frame_elems()); returns when the frame is complete
+ *                           tiles: rt_multi_frame_elems()); returns when the frame is complete. The shards write d_frame
+ *                           from their own streams: the buffer must be IDLE on entry (no pending work of the caller on it -
+ *                           synchronise the stream that last touched it first)
  *   rt_multi_context        the r-th context (rt_count_rays / rt_get_stats / rt_timing_* per shard) */
 typedef struct rt_multi rt_multi;
 int rt_create_multi(rt_multi** m, const void* objs, uint32_t n_objs, const void* lights, uint32_t n_lights,

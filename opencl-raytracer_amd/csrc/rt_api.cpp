@@ -104,6 +104,12 @@ struct rt_context {
     int nan_winner = -1;                    // the last sphere / box of the scene decides what a NaN ray ends with (rt_device.h)
     bool nan_winner_sphere = false;
     bool forced_literal = false;            // a degenerate instance switched the context to RT_FLAG_LITERAL (rt_create)
+    // Primary directions the exact eliminations are not made for - |d|^2 == 0, below 1e-30 or above 1e30 (or not finite): the
+    // reference's tests then produce NaN times for every object (.cl:85-108), which only the literal loops reproduce. Such a
+    // frame is rendered the literal way as a whole (apply_ray_domain): `flags` = base_flags | LITERAL while the rays in use
+    // (the uploaded buffer, or the pinhole camera that replaced it) hold such a direction.
+    uint32_t base_flags = 0;                // `flags` after rt_create's instance checks
+    bool rays_out_of_domain = false, camera_out_of_domain = false;
     bool affine_w = true;                   // every mv / mvInverse has bottom row (0,0,0,1) exactly
     bool primary_w_one = true;              // every uploaded primary ray has start.w == 1
     double origin_lo[3] = {0, 0, 0}, origin_hi[3] = {0, 0, 0};  // box of the primary ray origins
@@ -410,6 +416,25 @@ int ensure_host_out(rt_context* c) {
 // traversal loop dwarfs its per-round state traffic.
 constexpr uint32_t kWavefrontMinObjects = 512;      // brute-force wavefront
 constexpr uint32_t kWavefrontGridMinObjects = 96;   // wavefront when the conservative grid is available
+
+// |d|^2 exactly as the walks compute it (fp32, unfused, left to right) against their `tame` window
+bool direction_in_domain(float dx, float dy, float dz) {
+    const volatile float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    const volatile float s1 = xx + yy;
+    const float dd = s1 + zz;
+    return dd > 1.0e-30f && dd < 1.0e30f;
+}
+// a pinhole grid's directions are (col - W/2, (H - row) - H/2, z): the shortest belongs to the centre pixel, the longest to a corner
+bool camera_in_domain(uint32_t W, uint32_t H, float z) {
+    const double zz = (double)z * (double)z;
+    const double lo = zz + ((W & 1u) ? 0.25 : 0.0) + ((H & 1u) ? 0.25 : 0.0);
+    const double hi = zz + 0.25 * (double)W * (double)W + 0.25 * (double)H * (double)H;
+    return std::isfinite(zz) && lo > 1.0e-29 && hi < 1.0e29;  // (a decade inside the walks' window: fp32 rounding of the sum)
+}
+void apply_ray_domain(rt_context* c) {
+    const bool out = c->pinhole ? c->camera_out_of_domain : c->rays_out_of_domain;
+    c->flags = c->base_flags | (out ? RT_FLAG_LITERAL : 0u);
+}
 
 bool use_wavefront(const rt_context* c) {
     if (c->has_triangles) return true;
@@ -1455,7 +1480,13 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
         }
         const volatile float rstepv = (float)(rmax / 255.0 * (1.0 + 1e-5)), kstepv = (float)(std::max(kmax, 1e-3) / 255.0 * (1.0 + 1e-5));
         const float rstepf = rstepv, kstepf = kstepv;
-        ok = ok && rstepf > 0.f && std::isfinite(rstepf) && std::isfinite(kstepf) && (uint64_t)ranges.size() + total / 3 + ranges.size() < (1ull << 30);
+        // Block indices travel in 24 bits: the walks keep the position inside a block they come back to in bits 24+ of their
+        // cursor (rt_grid.h: kLtBlockIndexBits; trace_segment / walk_segment mask with kLtBlockIndexMask). Count the blocks the
+        // table will hold EXACTLY - a head per tile plus the further blocks of every chain - and keep the record form beyond
+        // that (round 3 checked heads + total / 3 against 2^30, which the masks do not honour: ADVICE r3).
+        uint64_t n_lt_blocks = ranges.size();
+        for (size_t t = 0; t < ranges.size(); ++t) n_lt_blocks += ranges[t].y > 3u ? (ranges[t].y - 1u) / 3u : 0u;
+        ok = ok && rstepf > 0.f && std::isfinite(rstepf) && std::isfinite(kstepf) && rt::light_tile_blocks_fit(n_lt_blocks);
         if (ok) {
             const size_t heads = ranges.size();
             std::vector<uint32_t> blk(8 * heads, 0u), bid(4 * heads, c->n_objs);
@@ -1660,6 +1691,7 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         const rt_object_data& o = static_cast<const rt_object_data*>(objs)[i];
         if (o.type <= 1u && !std::isfinite(object_bound(o).r)) { c->flags |= RT_FLAG_LITERAL; c->forced_literal = true; }
     }
+    c->base_flags = c->flags;
     if (rays && n_rays) {
         const rt_ray* r = static_cast<const rt_ray*>(rays);
         uint32_t W = 0, H = 0;
@@ -1669,10 +1701,13 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
             c->width = W;
             c->height = H;
             c->z = z;
+            c->camera_out_of_domain = !camera_in_domain(W, H, z);
         } else {
             bool w0 = true;
             for (uint64_t i = 0; i < n_rays && w0; ++i) w0 = (r[i].direction[3] == 0.0f);
             c->dir_w_zero = w0;
+            for (uint64_t i = 0; i < n_rays && !c->rays_out_of_domain; ++i)
+                c->rays_out_of_domain = !direction_in_domain(r[i].direction[0], r[i].direction[1], r[i].direction[2]);
             for (uint64_t i = 0; i < n_rays; ++i) {  // where do primary rays start? (grid margins need it)
                 if (r[i].start[3] != 1.0f || !std::isfinite(r[i].start[0] + r[i].start[1] + r[i].start[2])) { c->primary_w_one = false; break; }
                 for (int a = 0; a < 3; ++a) {
@@ -1686,6 +1721,7 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         }
     }
 #undef RT_TRY
+    apply_ray_domain(c);
     (void)hipDeviceSynchronize();
     c->setup.upload_ms = sw.lap_ms();
     if (n_objs >= kWavefrontGridMinObjects || (flags & RT_FLAG_WAVEFRONT) || c->has_triangles) {
@@ -1699,10 +1735,11 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         if (rc != RT_OK) return bail(rc);
         c->setup.grid_ms += sw.lap_ms();
     }
-    if (c->has_triangles && (!c->grid.enabled || (flags & (RT_FLAG_LITERAL | RT_FLAG_MONOLITHIC | RT_FLAG_NO_GRID)))) {
+    if (c->has_triangles && (!c->grid.enabled || (c->flags & (RT_FLAG_LITERAL | RT_FLAG_MONOLITHIC | RT_FLAG_NO_GRID)))) {
         fail(c, RT_ERR_INVALID_ARGUMENT,
              "triangle records (type 2, an extension of the reference's two primitives) are traced by the grid path only: "
-             "it needs affine instances, ray w = 1, and none of RT_FLAG_LITERAL / RT_FLAG_MONOLITHIC / RT_FLAG_NO_GRID");
+             "it needs affine instances, ray w = 1, primary directions with 1e-30 < |d|^2 < 1e30, and none of RT_FLAG_LITERAL / "
+             "RT_FLAG_MONOLITHIC / RT_FLAG_NO_GRID");
         return bail(RT_ERR_INVALID_ARGUMENT);
     }
     c->setup.create_ms = sw_total.lap_ms();
@@ -1721,7 +1758,12 @@ int rt_set_camera(rt_context* c, uint32_t width, uint32_t height, float z) {
     if (width == 0 || height == 0 || (uint64_t)width * height != c->n_rays)
         return fail(c, RT_ERR_INVALID_ARGUMENT, "width*height must equal n_rays");
     if (width > 0x1000000u || height > 0x1000000u) return fail(c, RT_ERR_INVALID_ARGUMENT, "grid too large");
+    const bool out = !camera_in_domain(width, height, z);
+    if (out && c->has_triangles)
+        return fail(c, RT_ERR_INVALID_ARGUMENT, "a camera with a direction of |d|^2 outside (1e-30, 1e30) needs the literal loops, which do not know triangle records");
+    c->camera_out_of_domain = out;
     c->pinhole = true;
+    apply_ray_domain(c);
     c->width = width;
     c->height = height;
     c->z = z;

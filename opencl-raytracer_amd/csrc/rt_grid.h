@@ -118,6 +118,14 @@ constexpr uint32_t kBlockBorder = 2;
 constexpr uint32_t kBlockEntries = RT_BLOCK_ENTRIES;
 static_assert(kBlockEntries >= 1 && kBlockEntries <= 7, "a block is a header word and up to seven 4-byte candidates");
 
+// Light-tile blocks (LightTiles::blocks) are addressed by 24-bit indices: a walk that has to come back to a block keeps the
+// entry to resume at in bits 24+ of its cursor. build_light_tiles refuses the block form for tables beyond that.
+constexpr uint32_t kLtBlockIndexBits = 24;
+constexpr uint32_t kLtBlockIndexMask = (1u << kLtBlockIndexBits) - 1u;
+__host__ __device__ constexpr bool light_tile_blocks_fit(uint64_t n_blocks) { return n_blocks < (1ull << kLtBlockIndexBits); }
+static_assert(light_tile_blocks_fit((1ull << 24) - 1) && !light_tile_blocks_fit(1ull << 24) && !light_tile_blocks_fit(9000000ull * 2),
+              "the last index a cursor can carry is 2^24 - 1");
+
 // Element `index` of a read-only table smaller than 4 GiB (build_grid / build_light_tiles refuse larger ones): the byte
 // offset is formed in 32 bits, so the load takes the scalar-base + 32-bit-vector-offset form instead of a 64-bit vector
 // address computed with two more vector instructions per load - the walk does three such loads per trip.

@@ -604,7 +604,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
         if (ANY && st == 4) {
             // ---- a light tile's block (state 4): three candidates per 32-byte fetch, as walk_segment's light-tile lanes ----
             const LightTiles& lt = w.ltiles;
-            const uint32_t b = e & 0xffffffu, pos = e >> 24;
+            const uint32_t b = e & kLtBlockIndexMask, pos = e >> kLtBlockIndexBits;
             const uint4 q0 = table_at(lt.blocks, 2u * b), q1 = table_at(lt.blocks, 2u * b + 1u);
             // (the block's ids are requested WITH the block, not after its pre-tests: 0.8 of a shadow ray's 1.1 blocks have a
             // candidate that passes, and the walk is a chain of dependent fetches - 16 bytes more per block, one step less per ray)
@@ -640,7 +640,7 @@ __device__ __forceinline__ void trace_segment(const WfParams& w, const uint32_t*
             pend = parked != 0u;
             blocked = stalled != 0u;
             st = (!blocked && (beyond || nxt == 0u)) ? 3 : 4;
-            e = blocked ? (b | (back << 24)) : nxt;
+            e = blocked ? (b | (back << kLtBlockIndexBits)) : nxt;
         }
         uint32_t skip = 0u;
         // how many of those a lane takes in one trip: few while the wave is full (the other lanes wait for it), all of them
@@ -953,7 +953,7 @@ __device__ __forceinline__ void walk_segment(const WfParams& w, const uint32_t* 
         if (ANY && walking && in_lt_blocks) {
             // ---- a light tile's block: three candidates per 32-byte fetch (the shadow walk was paying for 2.4 record fetches per ray)
             const LightTiles& lt = w.ltiles;
-            const uint32_t b = cursor & 0xffffffu, pos = cursor >> 24;
+            const uint32_t b = cursor & kLtBlockIndexMask, pos = cursor >> kLtBlockIndexBits;
             const uint4 q0 = table_at(lt.blocks, 2u * b), q1 = table_at(lt.blocks, 2u * b + 1u);
             // (the block's ids are requested WITH the block, not after its pre-tests: 0.8 of a shadow ray's 1.1 blocks have a
             // candidate that passes, and the walk is a chain of dependent fetches - 16 bytes more per block, one step less per ray)
@@ -988,7 +988,7 @@ __device__ __forceinline__ void walk_segment(const WfParams& w, const uint32_t* 
             pend = parked != 0u;
             stall = stalled != 0u;
             over = !stall && (beyond || nxt == 0u);
-            cursor = stall ? (b | (back << 24)) : nxt;
+            cursor = stall ? (b | (back << kLtBlockIndexBits)) : nxt;
         } else if (walking) {
             const float4 a = table_at(rec, 2u * cursor);
             const float4 b = table_at(rec, 2u * cursor + 1u);
@@ -1471,6 +1471,11 @@ template <bool FUSED, bool STATS, bool TRI>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TRI ? RT_WALK3_WAVES_TRI : RT_WALK3_WAVES))) void wf_walk_blocks(const WfParams wk, uint32_t* __restrict__ run_ctr) {
     WfParams w = wk;
     if (!resolve_round(w)) return;
+#ifdef RT_WALK3_LDS_PAD  // measurement knob: LDS nobody uses, so that only 160 KB / pad workgroups (x 4 waves) fit a CU
+    __shared__ uint32_t occupancy_pad[RT_WALK3_LDS_PAD / 4];
+    if (w.n_prev_closest == 0xffffffffu) occupancy_pad[threadIdx.x] = threadIdx.x;
+    asm volatile("" ::"v"(&occupancy_pad[0]));
+#endif
     const uint32_t n_queue = w.n_prev_closest;
     if (n_queue == 0u) return;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
@@ -2145,6 +2150,403 @@ __global__ __launch_bounds__(256) void wf_finish(const WfParams wk) {
     }
 }
 
+// ---- the frame in ONE persistent kernel (round 4) ------------------------------------------------------------------------
+// The reference's work-item runs primary ray -> shade -> up to D reflection iterations without ever waiting for another
+// pixel (shade_and_reflect_kernel.cl:244-285). The round machine above cuts that loop at every ray and puts a device-wide
+// barrier there: 5 rounds x {two walks, wf_resume, wf_advance} = 21 launches per cfg4 frame, every persistent walk draining
+// from 54 to 0 live lanes before the next kernel may start (~0.15 ms per launch that no split of the frame over more GPUs
+// removes), and a memory-bound wf_resume that runs alone between issue-bound walks. Here a LANE keeps its
+// pixel from the primary hit to the final store:
+//   * a lane whose closest-hit walk has ended does its pixel's next step ITSELF the next time rays are handed out
+//     (frame_step: materialise the hit, test the last light's shadow ray on the spot through the light tile - the list
+//     wf_resume's last hits and wf_finish already walk in one thread, last_light_blocked - shade, accumulate, build the
+//     reflection ray, test it against the object it leaves) and walks on with the new ray; a lane whose pixel has been
+//     written takes the next pixel of its wave's run. No queue, no pixel state in HBM, no second ray kind in flight: the
+//     accumulators (absorbColor, absorptionPercent, reflectColor, bounces) live in 32 bytes of LDS per lane, the ray and
+//     its result in the walk's registers;
+//   * the walk is block_segment's, trip for trip (same blocks, same pre-tests, same parked exact tests, same order-free
+//     update), so (t, index) of every ray are the round machine's bits; the step calls the round machine's own device
+//     functions, so every colour is too;
+//   * what a step cannot finish in this form - the light loop's backward scan has to go on to an earlier light (stale
+//     specular: lit with nDotL <= 0) - is handed to the round machine: the pixel's state BEFORE the step is written in
+//     wf_resume's format (ray in slot 0, accumulators, phase PH_PRIMARY / PH_REFLECT) and the pixel appended to the next
+//     closest-hit queue; wf_finish (or, should there be many, further rounds) re-traces that ray and carries on.
+// Used for shade_and_reflect frames through grid + block grid + block-form light tiles without triangles or always-tested
+// objects (launch: frame_kernel_applies); everything else keeps the rounds. Primary rays keep their own first kernel
+// (screen tiles: wave-uniform lists), whose (t, index) per work-item this kernel reads when it admits a pixel.
+#ifndef RT_FRAME_WAVES
+#define RT_FRAME_WAVES 4          // waves per SIMD the kernel is compiled for (128 registers: the step is wf_resume's arithmetic)
+#endif
+#ifndef RT_FRAME_REFILL_MIN
+#define RT_FRAME_REFILL_MIN 16    // steps / admissions run once this many lanes have one to do (a step is ~800 instructions)
+#endif
+struct FrameAcc {
+    float abr, abg, abb, ap;      // absorbColor, absorptionPercent (shade_and_reflect_kernel.cl:255-257)
+    float rr, rg, rb;             // reflectColor
+    uint32_t bounces;             // as the loop's unsigned counter AFTER its post-decrement
+};
+
+// shade()'s light loop for hit h where the LAST light decides the colour alone (resume_shadow's backward scan at its first
+// light, statement for statement; shade_last_light_inline has the same lines). False: the scan has to go on to an earlier light.
+template <bool FUSED>
+__device__ __forceinline__ bool shade_last_light_now(const WfParams& w, const HitRec& h, float& cr, float& cg, float& cb, float& absorb, uint32_t& tests) {
+    const Scene& S = w.rp.scene;
+    const uint32_t li = S.n_lights - 1u;
+    float nDotL, rDotV;
+    bool lit;
+    {
+        float nvx = h.nx, nvy = h.ny, nvz = h.nz;
+        normalize3_shading(S.fast_phong != 0u, nvx, nvy, nvz);
+        float vvx = -h.px, vvy = -h.py, vvz = -h.pz;
+        normalize3_shading(S.fast_phong != 0u, vvx, vvy, vvz);
+        LightGeom g;
+        light_geometry<FUSED>(S.lights[li], h, nvx, nvy, nvz, vvx, vvy, vvz, g, S.fast_phong != 0u);
+        nDotL = g.nDotL; rDotV = g.rDotV;
+        lit = !last_light_blocked<FUSED>(w, g.shadow, tests);
+    }
+    const LightRec L = S.lights[li];
+    const ColdObject* co = S.cold + h.index;
+    const float4 amb = co->amb_absorb, dif = co->dif_shine, spec = co->spec_type;
+    float dr = 0.f, dg = 0.f, db = 0.f, sr = 0.f, sg = 0.f, sb = 0.f;
+    const float ar = amb.x * L.ambient.x, ag = amb.y * L.ambient.y, ab = amb.z * L.ambient.z;
+    if (lit) {
+        const float nd = __builtin_fmaxf(nDotL, 0.f);
+        dr = (dif.x * L.diffuse.x) * nd; dg = (dif.y * L.diffuse.y) * nd; db = (dif.z * L.diffuse.z) * nd;
+    }
+    bool need_specular = true;
+    if (!lit) {
+        need_specular = false;
+    } else if (nDotL > 0) {
+        const float pw = specular_power(rDotV, dif.w, S.fast_phong != 0u);
+        sr = (spec.x * L.specular.x) * pw; sg = (spec.y * L.specular.y) * pw; sb = (spec.z * L.specular.z) * pw;
+        need_specular = false;
+    }
+    if (need_specular && li > 0u) return false;
+    cr = (ar + dr) + sr; cg = (ag + dg) + sg; cb = (ab + db) + sb;
+    absorb = amb.w;
+    return true;
+}
+
+// the pixel as the round machine wants to find it in a closest-hit queue: its ray not traced yet, its state in HBM
+__device__ __forceinline__ void frame_hand_over(const WfParams& w, uint32_t pix, bool primary, Ray ray, const FrameAcc& a) {
+    ray.sw = 1.0f;
+    ray.dw = __uint_as_float(0xffffffffu);  // no note for the walk: it tests the object the ray leaves like any other (begin_shade_lit)
+    store_ray(w, pix, ray, kSlotClosest);
+    if (primary) {
+        store_block(w, F_NX, pix, make_float4(0.f, 0.f, 0.f, __uint_as_float(PH_PRIMARY)));
+    } else {
+        store_block(w, F_ABR, pix, make_float4(a.abr, a.abg, a.abb, a.ap));
+        U(w, F_BOUNCES, pix) = a.bounces;
+        store_block(w, F_RR, pix, make_float4(a.rr, a.rg, a.rb, 0.f));
+        store_block(w, F_NX, pix, make_float4(0.f, 0.f, 0.f, __uint_as_float(PH_REFLECT)));
+    }
+    push(w.q_closest, &w.counts[RS_NEXT_CLOSEST], pix);
+}
+
+// One step of a pixel: its closest-hit ray `ray` came back with (T, idx). True: the pixel goes on with the reflection ray now
+// in `ray` (`note` = the object it leaves, already tested, or ~0). False: the pixel has been written - or handed over.
+template <bool FUSED>
+__device__ __forceinline__ bool frame_step(const WfParams& w, uint32_t pix, bool primary, Ray& ray, uint32_t& note, float T, int idx,
+                                           FrameAcc& a, Ctx& cnt) {
+    const RenderParams& p = w.rp;
+    const Scene& S = p.scene;
+    if (T == kMaxFloat) patch_nan_result(w, ray, T, idx);
+    const bool hit = !(T == kMaxFloat);
+    const uint64_t px = pixel_of(p, pix);
+    float4* out = reinterpret_cast<float4*>(p.out);
+    auto finish = [&]() {  // the tail of shade_and_reflect (:281-284): finish_reflect without the phase word
+        float abr = a.abr, abg = a.abg, abb = a.abb;
+        if (a.bounces == 0u && a.ap < 1.f) {
+            const float wgt = 1.f - a.ap;
+            abr = fma_<FUSED>(wgt, a.rr, abr); abg = fma_<FUSED>(wgt, a.rg, abg); abb = fma_<FUSED>(wgt, a.rb, abb);
+        }
+        out[px] = make_float4(abr, abg, abb, 1.0f);
+    };
+    if (primary) {
+        if (p.aux_t) p.aux_t[px] = T;
+        if (p.aux_index) p.aux_index[px] = hit ? idx : -1;
+        if (!hit) { cnt.traced += 1; cnt.reference += 1; out[px] = make_float4(0.f, 0.f, 0.f, 1.0f); return false; }
+    } else if (!hit) {  // raycast() false (:268)
+        finish();
+        return false;
+    }
+    HitRec h;
+    ObjRows rows;
+    float absorb_h;
+    materialise<FUSED>(S.objrec, S.cold, idx, T, ray, h, S.affine != 0u, &rows, &absorb_h);
+    float cr, cg, cb, absorb;
+    uint32_t tests = 0;
+    if (!shade_last_light_now<FUSED>(w, h, cr, cg, cb, absorb, tests)) {
+        frame_hand_over(w, pix, primary, ray, a);  // (nothing of this step has been counted or written)
+        return false;
+    }
+    if (primary) { cnt.traced += 1; cnt.reference += 1; cnt.hits += 1; }
+    cnt.traced += 1;               // the shadow ray just tested
+    cnt.reference += S.n_lights;   // the light loop's rays (begin_shade_lit)
+    cnt.tests += tests;
+    if (primary) {  // absorbColor = hit.mat.absorption * shade(hit) (:255-256); bounces = MAX_BOUNCES (:258)
+        a.ap = absorb;
+        a.abr = cr * a.ap; a.abg = cg * a.ap; a.abb = cb * a.ap;
+        a.rr = 0.f; a.rg = 0.f; a.rb = 0.f;
+        a.bounces = p.max_bounces;
+    } else {        // (:270-274)
+        const float ra = (1.f - a.ap) * absorb;
+        a.abr = fma_<FUSED>(ra, cr, a.abr); a.abg = fma_<FUSED>(ra, cg, a.abg); a.abb = fma_<FUSED>(ra, cb, a.abb);
+        a.ap = a.ap + ra;
+        a.rr = cr; a.rg = cg; a.rb = cb;
+    }
+    // top of `while (bounces-- > 0 && raycast(...) && absorptionPercent <= 0.999f)` (:268), as loop_step
+    const uint32_t before = a.bounces;
+    a.bounces = before - 1u;
+    if (!(before > 0u)) { finish(); return false; }
+    cnt.reference += 1;
+    if (!(a.ap <= 0.999f)) { finish(); return false; }  // the reference casts this ray but never reads its result
+    reflection_ray<FUSED>(h, ray);
+    float t_self;
+    bool sphere_self;
+    const bool self_hit = rows_candidate<FUSED, true>(rows, ray, t_self, sphere_self);  // begin_shade_lit: the ray's own object, tested here
+    note = self_hit ? 0xffffffffu : (uint32_t)h.index;
+    cnt.traced += 1;
+    return true;
+}
+
+template <bool FUSED, bool COUNT>
+__device__ __forceinline__ void frame_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue, uint32_t wave,
+                                              uint32_t n_waves, uint32_t* __restrict__ run_ctr, float4* __restrict__ s_acc, Ctx& cnt,
+                                              unsigned long long& tested) {
+    const uint32_t lane = threadIdx.x & 63u;
+    RunCursor rc;
+    if (!rc.begin(n_queue, wave, n_waves, run_ctr, lane)) return;
+    uint32_t& next = rc.next;
+    const uint32_t& seg_end = rc.seg_end;
+    bool more = rc.dynamic;
+    const GridDesc& g = w.grid;
+    const BlockGrid& bg = w.bgrid;
+    const HotObject* __restrict__ hot = w.rp.scene.hot;
+    const float wnx_f = (float)bg.wnx, wny_f = (float)bg.wny;
+    float4* my_acc = s_acc + 2u * threadIdx.x;  // this lane's FrameAcc between steps (nobody else reads it: no barrier anywhere)
+
+    constexpr uint32_t kAlive = 1u;    // the lane holds a ray that is being walked ...
+    constexpr uint32_t kOver = 2u;     // ... whose walk has ended (it may still wait for its parked exact test)
+    constexpr uint32_t kPend = 4u;     // a candidate is parked for the next round of exact tests (pend_k)
+    constexpr uint32_t kSphere = 8u;   // the current best hit is a sphere (closest_take's tie rule)
+    constexpr uint32_t kDone = 16u;    // the lane holds a ray whose result (T, idx) is final: its pixel's step is due
+    uint32_t fl = 0u;
+    uint32_t pix = 0;
+    float rsx = 0.f, rsy = 0.f, rsz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, dd = 0.f;
+    uint32_t cur = 0;
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    float tx = 0.f, ty = 0.f, tz = 0.f, dtx = 0.f, dty = 0.f, dtz = 0.f;
+    float T = kMaxFloat, limit = 0.f, t_stop = 0.f, slack = 0.f;
+    int idx = -1;
+    uint32_t pend_k = 0, done_k = 0xffffffffu;
+
+    for (;;) {
+        if (next >= seg_end && more) more = rc.grab(n_queue, run_ctr, lane);  // on to another run, if any is left
+        // ---- steps of the pixels whose ray has come back, new pixels for the lanes whose pixel has been written ----
+        const unsigned long long idle = __ballot((fl & kAlive) == 0u);
+        const unsigned long long due = __ballot((fl & kDone) != 0u);
+        const uint32_t n_due = (uint32_t)__popcll(due), n_empty = (uint32_t)__popcll(idle) - n_due;
+        const uint32_t left = next < seg_end ? seg_end - next : 0u;
+        const uint32_t ready = n_due + (n_empty < left ? n_empty : left);
+        if (ready != 0u && (ready >= (uint32_t)RT_FRAME_REFILL_MIN || idle == ~0ull)) {
+#pragma nounroll
+            for (int pass = 0; pass < 2; ++pass) {
+                // pass 0: the lanes whose ray has come back; pass 1: the lanes without a pixel (those of pass 0 whose pixel ended included)
+                bool run = false, primary = false;
+                if (pass == 0) {
+                    run = (fl & kDone) != 0u;
+                } else {
+                    const bool empty = (fl & (kAlive | kDone)) == 0u;
+                    const unsigned long long em = __ballot(empty);
+                    const uint32_t mine = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+                    if (empty && mine < seg_end) {
+                        const uint32_t entry = w.identity_queue ? mine : queue[mine];
+                        pix = w.identity_queue ? mine : (entry & kQueuePixel);
+                        load_closest_result(w, pix, T, idx);   // the first kernel's (t, index) of this work-item's primary ray
+                        const Ray pr = closest_ray(w, pix, true);
+                        rsx = pr.sx; rsy = pr.sy; rsz = pr.sz; rdx = pr.dx; rdy = pr.dy; rdz = pr.dz;
+                        run = true;
+                        primary = true;
+                    }
+                    const uint32_t n_em = (uint32_t)__popcll(em), room = next < seg_end ? seg_end - next : 0u;
+                    next += n_em < room ? n_em : room;
+                }
+                if (__ballot(run) == 0ull) continue;
+                if (run) {
+                    Ray ray = {rsx, rsy, rsz, 1.0f, rdx, rdy, rdz, 0.0f};  // (what every ray of a grid-able frame carries: rt_create checks)
+                    FrameAcc a;
+                    if (!primary) {
+                        const float4 a0 = my_acc[0], a1 = my_acc[1];
+                        a.abr = a0.x; a.abg = a0.y; a.abb = a0.z; a.ap = a0.w;
+                        a.rr = a1.x; a.rg = a1.y; a.rb = a1.z; a.bounces = __float_as_uint(a1.w);
+                    } else {
+                        a = FrameAcc{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u};
+                    }
+                    uint32_t note = 0xffffffffu;
+                    const bool goes_on = frame_step<FUSED>(w, pix, primary, ray, note, T, idx, a, cnt);
+                    fl = 0u;
+                    if (goes_on) {
+                        my_acc[0] = make_float4(a.abr, a.abg, a.abb, a.ap);
+                        my_acc[1] = make_float4(a.rr, a.rg, a.rb, __uint_as_float(a.bounces));
+                        // ---- the new ray's walk (block_segment's hand-out) ----
+                        rsx = ray.sx; rsy = ray.sy; rsz = ray.sz; rdx = ray.dx; rdy = ray.dy; rdz = ray.dz;
+                        ray.sw = 1.0f; ray.dw = 0.0f;
+                        T = kMaxFloat; idx = -1;
+                        bool cur_sphere = false;
+                        done_k = note;
+                        dd = rdx * rdx + rdy * rdy + rdz * rdz;
+                        slack = dd > 0.f ? kWalkSlackCells * bg.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
+                        bool start = false, brute = false;
+                        const Walk w0 = walk_begin(bg, ray, 3.0e38f);  // (a ray with a NaN in it: not alive)
+                        if (w0.alive) {
+                            const float dmin = __builtin_fminf(__builtin_fminf(w0.dtx, w0.dty), w0.dtz);
+                            const bool tame = dd > 1.0e-30f && dd < 1.0e30f && w0.t_enter <= 4096.f * dmin;
+                            brute = !tame;
+                            start = tame;
+                            fx = (float)(w0.ix + (int)kBlockBorder); fy = (float)(w0.iy + (int)kBlockBorder); fz = (float)(w0.iz + (int)kBlockBorder);
+                            cur = ((uint32_t)(w0.iz + (int)kBlockBorder) * bg.wny + (uint32_t)(w0.iy + (int)kBlockBorder)) * bg.wnx + (uint32_t)(w0.ix + (int)kBlockBorder);
+                            tx = w0.tx; ty = w0.ty; tz = w0.tz; dtx = w0.dtx; dty = w0.dty; dtz = w0.dtz;
+                            t_stop = __builtin_fminf(w0.t_exit + 0.25f * dmin, 3.0e38f);
+                        }
+                        if (brute) {  // a ray the walk is not made for (a direction of absurd magnitude) tests every object, here and now
+                            for (uint32_t k = 0; k < w.rp.scene.n_objs; ++k) {
+                                float t;
+                                bool sphere;
+                                const bool cand = lane_candidate<FUSED, true, false>(hot + k, ray, t, sphere);
+                                if (COUNT) ++tested;
+                                if (cand) closest_take(t, (int)k, sphere, T, idx, cur_sphere);
+                            }
+                        }
+                        limit = __builtin_fminf(T + slack, t_stop);
+                        // no cell to look at, or everything tested already: the result is final, the next step is due
+                        fl = start ? (kAlive | (cur_sphere ? kSphere : 0u)) : kDone;
+                    }
+                }
+            }
+        }
+        const unsigned long long live = __ballot((fl & kAlive) != 0u);
+        if (live == 0ull) {
+            if (__ballot((fl & kDone) != 0u) == 0ull && next >= seg_end && !more) break;
+            continue;
+        }
+        // ---- one trip: the block under the cursor (block_segment, trip for trip) ----
+        const bool walking = (fl & (kAlive | kOver)) == kAlive;
+        uint32_t stalled = 0u;
+        if (walking) {
+            const uint32_t b = cur & 0xffffffu, pos = cur >> 24;
+            const uint4 q0 = table_at(bg.blocks, 2u * b);
+            const uint4 q1 = table_at(bg.blocks, 2u * b + 1u);
+            const uint32_t nxt = q0.x & 0xffffffu;
+            const float inv = __builtin_ldexpf(bg.inv_step, -(int)((q0.x >> 27) & 3u));
+            const float olx = __builtin_fmaf(rsx - __builtin_fmaf(fx, bg.cell, bg.c0x), inv, 128.0f);
+            const float oly = __builtin_fmaf(rsy - __builtin_fmaf(fy, bg.cell, bg.c0y), inv, 128.0f);
+            const float olz = __builtin_fmaf(rsz - __builtin_fmaf(fz, bg.cell, bg.c0z), inv, 128.0f);
+            uint32_t pm = block_pretests(q0, q1, olx, oly, olz, rdx, rdy, rdz, -dd, 1.0f - g.pretest_alpha);
+            pm &= 0x7fu << pos;
+            uint32_t back = 0u;
+            while (pm != 0u) {
+                const uint32_t e = (uint32_t)__builtin_ctz(pm);
+                const uint32_t k = table_at(bg.ids, 8u * b + e);
+                const bool parked = (fl & kPend) != 0u;
+                const bool dup = (k == done_k) || (parked && k == pend_k);
+                const bool wait = !dup && parked;
+                const bool take = !dup && !parked;
+                pend_k = take ? k : pend_k;
+                fl |= take ? kPend : 0u;
+                stalled = wait ? 1u : stalled;
+                back = wait ? e : back;
+                pm = wait ? 0u : (pm & (pm - 1u));
+            }
+            const bool adv = stalled == 0u && nxt == 0u;
+            const float tmin = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+            const bool ax = (tx <= ty) && (tx <= tz);
+            const bool ay = !ax && (ty <= tz);
+            const bool az = !ax && !ay;
+            tx += (adv && ax) ? dtx : 0.f;
+            ty += (adv && ay) ? dty : 0.f;
+            tz += (adv && az) ? dtz : 0.f;
+            fx += (adv && ax) ? __builtin_copysignf(1.0f, rdx) : 0.f;
+            fy += (adv && ay) ? __builtin_copysignf(1.0f, rdy) : 0.f;
+            fz += (adv && az) ? __builtin_copysignf(1.0f, rdz) : 0.f;
+            fl |= (adv && tmin > limit) ? kOver : 0u;
+            {
+                uint32_t skips = ((q0.x >> 24) & 7u) | ((q0.x >> 26) & 0x38u);
+                skips = (adv && (fl & kOver) == 0u) ? (skips < (uint32_t)RT_BLOCK_SKIP_CAP ? skips : (uint32_t)RT_BLOCK_SKIP_CAP) : 0u;
+                if (!bg.take_skips) skips = 0u;
+                while (skips != 0u) {
+                    const float tm = __builtin_fminf(__builtin_fminf(tx, ty), tz);
+                    const bool sx = (tx <= ty) && (tx <= tz);
+                    const bool sy = !sx && (ty <= tz);
+                    const bool sz = !sx && !sy;
+                    tx += sx ? dtx : 0.f;
+                    ty += sy ? dty : 0.f;
+                    tz += sz ? dtz : 0.f;
+                    fx += sx ? __builtin_copysignf(1.0f, rdx) : 0.f;
+                    fy += sy ? __builtin_copysignf(1.0f, rdy) : 0.f;
+                    fz += sz ? __builtin_copysignf(1.0f, rdz) : 0.f;
+                    const bool outside = tm > limit;
+                    fl |= outside ? kOver : 0u;
+                    skips = outside ? 0u : skips - 1u;
+                }
+            }
+            const uint32_t cell = (uint32_t)__builtin_fmaf(__builtin_fmaf(fz, wny_f, fy), wnx_f, fx);
+            cur = stalled != 0u ? (b | (back << 24)) : (adv ? cell : nxt);
+        }
+        // ---- the exact tests, when enough lanes wait for them ----
+        const unsigned long long pending = __ballot((fl & kPend) != 0u);
+        if (pending != 0ull) {
+            const unsigned long long stuck = __ballot((fl & kPend) != 0u && (stalled != 0u || (fl & kOver) != 0u));
+            const uint32_t n_live = (uint32_t)__popcll(live);
+            if ((uint32_t)__popcll(pending) >= (uint32_t)RT_WALK3_DEFER_PENDING || ((uint32_t)__popcll(stuck) << RT_WALK3_STUCK_SHIFT) >= n_live) {
+                if ((fl & kPend) != 0u) {
+                    float t;
+                    bool sphere;
+                    const Ray ray = {rsx, rsy, rsz, 1.0f, rdx, rdy, rdz, 0.0f};
+                    const bool cand = lane_candidate<FUSED, true, false>(hot + pend_k, ray, t, sphere);
+                    if (COUNT) ++tested;
+                    done_k = pend_k;
+                    bool cur_sphere = (fl & kSphere) != 0u;
+                    if (cand) {
+                        closest_take(t, (int)pend_k, sphere, T, idx, cur_sphere);
+                        limit = __builtin_fminf(T + slack, t_stop);
+                    }
+                    fl = (fl & ~(kPend | kSphere)) | (cur_sphere ? kSphere : 0u);
+                }
+            }
+        }
+        // ---- a finished walk with nothing parked: the ray's result is final, its pixel's step is due ----
+        if ((fl & (kAlive | kOver | kPend)) == (kAlive | kOver)) fl = kDone;
+    }
+}
+
+template <bool FUSED, bool COUNT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_FRAME_WAVES, RT_FRAME_WAVES))) void wf_frame(const WfParams wk, uint32_t* __restrict__ run_ctr) {
+    WfParams w = wk;
+    if (!resolve_round(w)) return;
+    __shared__ float4 s_acc[2 * 256];
+    const uint32_t n_queue = w.n_prev_closest;
+    if (n_queue == 0u) return;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * 256u) >> 6;
+    Ctx cnt{w, 0, 0ull, 0ull, 0ull, false, false, 0u, 0u, make_float4(0.f, 0.f, 0.f, 0.f), false, {}, {}, {}, {}};
+    unsigned long long tested = 0;
+    frame_segment<FUSED, COUNT>(w, w.q_prev_closest, n_queue, wave, n_waves, run_ctr, s_acc, cnt, tested);
+    if (COUNT) {
+        add_ray_counters(w, cnt);
+        if (tested) atomicAdd(&w.rp.counters->tests, tested);
+    }
+}
+
+// the frames wf_frame is made for (everything else keeps the round machine)
+static bool frame_kernel_applies(const WfParams& w, int kernel) {
+    const char* env = std::getenv("RT_FRAME_KERNEL");  // "1": on (read per launch: tests render both ways in one process)
+    if (!(env && env[0] == '1')) return false;
+    if (std::getenv("RT_WALK2") || std::getenv("RT_WALK3")) return false;  // (a run that asks for one of the round machine's walks by name)
+    return kernel == 2 && w.grid.enabled && !w.rp.scene.literal && !w.grid.has_triangles && w.grid.n_always == 0u && w.bgrid.enabled &&
+           w.ltiles.enabled && w.ltiles.blocks_enabled && w.rp.scene.n_lights >= 1u && w.ltiles.light == w.rp.scene.n_lights - 1u;
+}
+
 constexpr uint32_t kMinSlicePairs = 2048;
 constexpr uint32_t kMaxSlices = 16;
 
@@ -2288,6 +2690,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
     }
 
     static const bool one_stream = std::getenv("RT_WF_ONE_STREAM") != nullptr;  // measurement knob
+    const bool use_frame = KERNEL == 2 && frame_kernel_applies(w, KERNEL);
     auto enqueue_round = [&](bool first, uint64_t nc_max, uint64_t na_max) -> hipError_t {
         hipError_t e2;
         w.first_round = first ? 1u : 0u;
@@ -2347,8 +2750,18 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
             }
         }
         const uint64_t total_max = nc_max + na_max;
-        hipLaunchKernelGGL((wf_resume<KERNEL, FUSED>), dim3((uint32_t)((total_max + kResumeThreads - 1) / kResumeThreads)),
-                           dim3(kResumeThreads), 0, stream, w);
+        if (first && use_frame) {
+            // wf_frame: every pixel from its primary hit to its final store in one persistent launch (the first round's shadow
+            // tickets are unused: the first round traces primary rays only)
+            uint64_t waves = 256ull * 4ull * (uint64_t)RT_FRAME_WAVES;  // every wave that can be resident
+            if (const char* env = std::getenv("RT_WAVES_FRAME")) waves = (uint64_t)std::max(64, std::atoi(env));  // measurement knob
+            const dim3 grid = persistent_grid(nc_max, waves);
+            if (w.count_rays) hipLaunchKernelGGL((wf_frame<FUSED, true>), grid, dim3(256), 0, stream, w, rs + kTicketBase + kTicketWords);
+            else hipLaunchKernelGGL((wf_frame<FUSED, false>), grid, dim3(256), 0, stream, w, rs + kTicketBase + kTicketWords);
+        } else {
+            hipLaunchKernelGGL((wf_resume<KERNEL, FUSED>), dim3((uint32_t)((total_max + kResumeThreads - 1) / kResumeThreads)),
+                               dim3(kResumeThreads), 0, stream, w);
+        }
         if ((e2 = hipGetLastError()) != hipSuccess) return e2;
         hipLaunchKernelGGL(wf_advance, dim3(1), dim3(256), 0, stream, rs, (uint32_t)finish_threshold, use_grid ? 1u : 0u);
         return hipGetLastError();
@@ -2360,6 +2773,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
     if (KERNEL == 1) batch = w.rp.scene.n_lights + 1u;
     else if (KERNEL == 2) batch = w.rp.scene.literal ? 8u : w.rp.max_bounces + 2u;
     if (batch > 12u) batch = 12u;
+    if (use_frame) batch = 1u;  // the first "round" is the whole frame; what it hands over goes to wf_finish (or, if many, to further rounds)
     if (const char* env = std::getenv("RT_WF_BATCH")) batch = (uint32_t)std::max(1, std::atoi(env));
     bool first = true;
     uint64_t nc_max = n, na_max = 0;  // the first round traces the primary rays only

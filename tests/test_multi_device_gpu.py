@@ -40,6 +40,7 @@ def test_grid_path_camera_mode_and_device_frame():
     with MultiHIPRaytracer(objs, lights, None, 3, devices=[0, 0, 0], camera=(W, H, z)) as rt:
         got = rt.Render()
         frame = torch.full((rt.frame_elems, 4), float("nan"), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()  # hip_raytracer.h: the frame must be idle on entry (the shards write it from their own streams)
         rt.render_device(frame.data_ptr())
         dev = frame[: W * H].cpu().numpy()
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
