@@ -127,7 +127,10 @@ def host_cores():
 
 
 def cpu_baseline(objs, lights, rays, kernel, depth, sample_desc):
-    """The oracle (CPU restatement, kind 'port') on a bounded sample of the same workload, all host cores."""
+    """A bounded sample of the same workload on the host's cores: the REFERENCE's own kernels where oracle/_ref exists (the
+    three .cl files compiled verbatim for the host in the build container - kind 'reference'; the library travels to the GPU
+    box with the snapshot, the sources do not), else the oracle's CPU restatement (kind 'port'). Both trace every ray the
+    reference traces; the restatement's time is reported beside the reference's."""
     from oracle import oracle
     rs = oracle.Restatement(True)
     threads = host_cores()
@@ -141,8 +144,29 @@ def cpu_baseline(objs, lights, rays, kernel, depth, sample_desc):
         best = dt if best is None else min(best, dt)
         if t_total > 12.0:
             break
-    return {"value": res["rays_ref"] / best / 1e6, "unit": "Mrays/s", "cores": int(res["threads"]), "kind": "port",
+    port = {"value": res["rays_ref"] / best / 1e6, "unit": "Mrays/s", "cores": int(res["threads"]), "kind": "port",
             "sample": sample_desc, "seconds": best}
+    try:
+        if not oracle.reference_available():
+            return port
+        ref = oracle.Reference(kernel, True)
+        best_ref, t_total, used = None, 0.0, 0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            used = ref.render(objs, lights, rays, depth, threads=threads)["threads"]
+            dt = time.perf_counter() - t0
+            t_total += dt
+            best_ref = dt if best_ref is None else min(best_ref, dt)
+            if t_total > 12.0:
+                break
+        return {"value": res["rays_ref"] / best_ref / 1e6, "unit": "Mrays/s", "cores": int(used), "kind": "reference",
+                "sample": sample_desc, "seconds": best_ref,
+                "what": "the reference's shade_and_reflect / shade / hittest kernels compiled verbatim for the host (oracle/_ref, OpenMP over "
+                        "work-items; OpenCL builtins from oracle/ref_shim.cl) - no OpenCL CPU device exists on this box",
+                "port": port}
+    except Exception as ex:  # noqa: BLE001  (an optional leg must never cost the line)
+        port["reference_unavailable"] = f"{type(ex).__name__}: {ex}"
+        return port
 
 
 def cpu_backend_baseline(objs, lights, rays, kernel, depth, sample_desc):

@@ -45,8 +45,12 @@ extern "C" {
  *   2  rt_render_device(ctx, out, NULL) means the LEGACY DEFAULT stream (it was the context's private stream in early
  *      builds of version 1); rt_get_setup_times; the multi-device entry points rt_create_multi / rt_render_multi /
  *      rt_render_multi_device / rt_multi_context / rt_destroy_multi. A caller built against version 1 keeps working:
- *      no existing signature or struct changed. */
-#define RT_ABI_VERSION 2
+ *      no existing signature or struct changed.
+ *   3  rt_get_stats_multi / rt_count_rays_multi (the counters of every shard, summed); rt_render_multi places every device's
+ *      tiles straight in the pinned host frame (no hop through devices[0]); rt_create / rt_set_camera switch a frame whose
+ *      primary directions leave the default path's domain (|d|^2 == 0, < 1e-30, > 1e30) to RT_FLAG_LITERAL by themselves.
+ *      Additions only: a caller built against version 2 keeps working. */
+#define RT_ABI_VERSION 3
 
 typedef struct rt_context rt_context;
 
@@ -190,7 +194,12 @@ void rt_destroy(rt_context* ctx);
  *                           tiles: rt_multi_frame_elems()); returns when the frame is complete. The shards write d_frame
  *                           from their own streams: the buffer must be IDLE on entry (no pending work of the caller on it -
  *                           synchronise the stream that last touched it first)
- *   rt_multi_context        the r-th context (rt_count_rays / rt_get_stats / rt_timing_* per shard) */
+ *   rt_multi_context        the r-th context (rt_count_rays / rt_get_stats / rt_timing_* per shard)
+ *   rt_count_rays_multi     the untimed counted render on every shard
+ *   rt_get_stats_multi      rays_traced / rays_reference / hit_pixels / object_tests / local_rays summed over the shards,
+ *                           last_kernel_ms and rounds of the slowest one (the whole frame's figures, like Render()'s frame)
+ * rt_render_multi: every device copies ITS tiles from its own memory into the pinned (portable) host frame, on its own
+ * stream and PCIe link (one strided device-to-host copy per shard); nothing is gathered on devices[0]. */
 typedef struct rt_multi rt_multi;
 int rt_create_multi(rt_multi** m, const void* objs, uint32_t n_objs, const void* lights, uint32_t n_lights,
                     const void* rays, uint64_t n_rays, uint32_t max_bounces, int kernel,
@@ -199,6 +208,8 @@ int rt_set_camera_multi(rt_multi* m, uint32_t width, uint32_t height, float z);
 uint64_t rt_multi_frame_elems(const rt_multi* m);
 int rt_render_multi(rt_multi* m, const float** out);
 int rt_render_multi_device(rt_multi* m, void* d_frame);
+int rt_count_rays_multi(rt_multi* m);
+int rt_get_stats_multi(rt_multi* m, rt_stats_t* stats);
 rt_context* rt_multi_context(rt_multi* m, uint32_t r);
 const char* rt_multi_last_error(const rt_multi* m);
 void rt_destroy_multi(rt_multi* m);

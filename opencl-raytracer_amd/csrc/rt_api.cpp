@@ -17,6 +17,8 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -1958,9 +1960,21 @@ struct rt_multi {
     std::vector<char> peer_ok;       // per context: devices[0] and its device can address each other's memory
     uint64_t n_rays = 0, tile_rays = 0, tiles = 0;
     size_t elem = 16;
-    void* d_frame = nullptr;         // rt_render_multi's frame on devices[0] (whole tiles)
-    void* h_frame = nullptr;         // ... and its pinned host copy
+    void* h_frame = nullptr;         // rt_render_multi's frame: pinned, portable host memory (whole tiles) every device copies its tiles into
     std::string error;
+    // One host thread per further shard, alive from rt_create_multi to rt_destroy_multi (round 3 created and joined n - 1
+    // threads per frame). A frame = one job: every worker renders its shard and puts its tiles in place, the calling thread
+    // does shard 0 and waits for the others.
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    uint64_t generation = 0;         // bumped per job
+    uint32_t pending = 0;            // workers that have not finished the current job
+    bool quit = false;
+    void* job_target = nullptr;      // where the tiles go: a frame on devices[0], or the pinned host frame
+    bool job_to_host = false;
+    std::vector<int> rcs;
+    std::vector<std::string> errs;
 };
 
 namespace {
@@ -1973,8 +1987,10 @@ int multi_fail(rt_multi* m, int code, const std::string& msg) {
     return code;
 }
 
-// one shard: render on the context's own stream, then put its tiles where they belong in the frame on devices[0]
-int multi_render_shard(rt_multi* m, uint32_t r, void* d_frame, std::string& err) {
+// one shard: render on the context's own stream, then put its tiles where they belong - in the frame on devices[0]
+// (rt_render_multi_device) or STRAIGHT in the pinned host frame (rt_render_multi: the reference's blocking read-back,
+// OpenCLRaytracer.cpp:94, over every GPU's own PCIe link at once instead of a hop to devices[0] and one link for the lot)
+int multi_render_shard(rt_multi* m, uint32_t r, void* frame, bool to_host, std::string& err) {
     rt_context* c = m->ctx[r];
     DeviceGuard guard(c->device);
     if (!guard.ok) { err = std::string("hipSetDevice: ") + hipGetErrorString(guard.err); return RT_ERR_HIP; }
@@ -1985,9 +2001,11 @@ int multi_render_shard(rt_multi* m, uint32_t r, void* d_frame, std::string& err)
     const size_t tile_bytes = (size_t)m->tile_rays * m->elem;
     hipError_t e = hipSuccess;
     if (mine) {
-        char* dst = static_cast<char*>(d_frame) + (size_t)r * tile_bytes;
-        if (c->device == m->devices[0] || m->peer_ok[r]) {
-            // tile j of this shard is tile j * n + r of the frame: one strided copy
+        // tile j of this shard is tile j * n + r of the frame: one strided copy
+        char* dst = static_cast<char*>(frame) + (size_t)r * tile_bytes;
+        if (to_host) {
+            e = hipMemcpy2DAsync(dst, (size_t)n * tile_bytes, m->d_local[r], tile_bytes, tile_bytes, (size_t)mine, hipMemcpyDeviceToHost, c->stream);
+        } else if (c->device == m->devices[0] || m->peer_ok[r]) {
             e = hipMemcpy2DAsync(dst, (size_t)n * tile_bytes, m->d_local[r], tile_bytes, tile_bytes, (size_t)mine, hipMemcpyDeviceToDevice, c->stream);
         } else {
             for (uint64_t j = 0; j < mine && e == hipSuccess; ++j)
@@ -2000,6 +2018,54 @@ int multi_render_shard(rt_multi* m, uint32_t r, void* d_frame, std::string& err)
     return RT_OK;
 }
 
+void multi_worker(rt_multi* m, uint32_t r) {
+    uint64_t seen = 0;
+    for (;;) {
+        void* target;
+        bool to_host;
+        {
+            std::unique_lock<std::mutex> lk(m->mu);
+            m->cv_go.wait(lk, [&] { return m->quit || m->generation != seen; });
+            if (m->quit) return;
+            seen = m->generation;
+            target = m->job_target;
+            to_host = m->job_to_host;
+        }
+        std::string err;
+        const int rc = multi_render_shard(m, r, target, to_host, err);
+        {
+            std::lock_guard<std::mutex> lk(m->mu);
+            m->rcs[r] = rc;
+            m->errs[r] = err;
+            if (--m->pending == 0) m->cv_done.notify_all();
+        }
+    }
+}
+
+// every shard renders and places its tiles; returns when the frame is complete
+int multi_run_frame(rt_multi* m, void* target, bool to_host) {
+    const uint32_t n = (uint32_t)m->ctx.size();
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->job_target = target;
+        m->job_to_host = to_host;
+        m->pending = (uint32_t)m->workers.size();
+        m->generation += 1;
+    }
+    m->cv_go.notify_all();
+    std::string err0;
+    const int rc0 = multi_render_shard(m, 0, target, to_host, err0);
+    {
+        std::unique_lock<std::mutex> lk(m->mu);
+        m->cv_done.wait(lk, [&] { return m->pending == 0; });
+        m->rcs[0] = rc0;
+        m->errs[0] = err0;
+    }
+    for (uint32_t r = 0; r < n; ++r)
+        if (m->rcs[r] != RT_OK) return multi_fail(m, m->rcs[r], "shard " + std::to_string(r) + ": " + m->errs[r]);
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2008,6 +2074,12 @@ const char* rt_multi_last_error(const rt_multi* m) { return m ? m->error.c_str()
 
 void rt_destroy_multi(rt_multi* m) {
     if (!m) return;
+    {
+        std::lock_guard<std::mutex> lk(m->mu);
+        m->quit = true;
+    }
+    m->cv_go.notify_all();
+    for (std::thread& t : m->workers) t.join();
     for (size_t r = 0; r < m->ctx.size(); ++r) {
         if (m->ctx[r] && r < m->d_local.size() && m->d_local[r]) {
             DeviceGuard guard(m->ctx[r]->device);
@@ -2017,7 +2089,6 @@ void rt_destroy_multi(rt_multi* m) {
     }
     if (!m->devices.empty()) {
         DeviceGuard guard(m->devices[0]);
-        if (m->d_frame) (void)hipFree(m->d_frame);
         if (m->h_frame) (void)hipHostFree(m->h_frame);
     }
     delete m;
@@ -2086,6 +2157,9 @@ int rt_create_multi(rt_multi** out, const void* objs, uint32_t n_objs, const voi
             return code;
         }
     }
+    m->rcs.assign(n_devices, RT_OK);
+    m->errs.assign(n_devices, std::string());
+    for (uint32_t r = 1; r < n_devices; ++r) m->workers.emplace_back(multi_worker, m, r);
     *out = m;
     return RT_OK;
 }
@@ -2106,32 +2180,57 @@ rt_context* rt_multi_context(rt_multi* m, uint32_t r) { return (m && r < m->ctx.
 int rt_render_multi_device(rt_multi* m, void* d_frame) {
     if (!m) return RT_ERR_INVALID_ARGUMENT;
     if (!d_frame && m->n_rays) return multi_fail(m, RT_ERR_INVALID_ARGUMENT, "d_frame is NULL");
-    const uint32_t n = (uint32_t)m->ctx.size();
-    std::vector<int> rcs(n, RT_OK);
-    std::vector<std::string> errs(n);
-    std::vector<std::thread> workers;
-    for (uint32_t r = 1; r < n; ++r) workers.emplace_back([&, r]() { rcs[r] = multi_render_shard(m, r, d_frame, errs[r]); });
-    rcs[0] = multi_render_shard(m, 0, d_frame, errs[0]);
-    for (std::thread& t : workers) t.join();
-    for (uint32_t r = 0; r < n; ++r)
-        if (rcs[r] != RT_OK) return multi_fail(m, rcs[r], "shard " + std::to_string(r) + ": " + errs[r]);
-    return RT_OK;
+    return multi_run_frame(m, d_frame, false);
 }
 
 int rt_render_multi(rt_multi* m, const float** out) {
     if (!m || !out) return RT_ERR_INVALID_ARGUMENT;
-    DeviceGuard guard(m->devices[0]);
-    if (!guard.ok) return multi_fail(m, RT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
-    const size_t frame_bytes = (size_t)rt_multi_frame_elems(m) * m->elem, want = (size_t)m->n_rays * m->elem;
-    hipError_t e = hipSuccess;
-    if (!m->d_frame) e = hipMalloc(&m->d_frame, frame_bytes ? frame_bytes : 16);
-    if (e == hipSuccess && !m->h_frame) e = hipHostMalloc(&m->h_frame, want ? want : 16, hipHostMallocDefault);
-    if (e != hipSuccess) return multi_fail(m, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, std::string("frame buffers: ") + hipGetErrorString(e));
-    const int rc = rt_render_multi_device(m, m->d_frame);
+    if (!m->h_frame) {
+        // whole tiles (the last one may be ragged: its padding work-items are written like pixels), pinned and PORTABLE: every
+        // device of the node copies into it
+        DeviceGuard guard(m->devices[0]);
+        if (!guard.ok) return multi_fail(m, RT_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(guard.err));
+        const size_t frame_bytes = (size_t)rt_multi_frame_elems(m) * m->elem;
+        const hipError_t e = hipHostMalloc(&m->h_frame, frame_bytes ? frame_bytes : 16, hipHostMallocPortable);
+        if (e != hipSuccess) return multi_fail(m, e == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_HIP, std::string("host frame: ") + hipGetErrorString(e));
+    }
+    const int rc = multi_run_frame(m, m->h_frame, true);  // Render() is synchronous (OpenCLRaytracer.cpp:94): every shard has waited for its copy
     if (rc != RT_OK) return rc;
-    if (want) e = hipMemcpy(m->h_frame, m->d_frame, want, hipMemcpyDeviceToHost);  // Render() is synchronous (OpenCLRaytracer.cpp:94)
-    if (e != hipSuccess) return multi_fail(m, RT_ERR_HIP, std::string("read-back: ") + hipGetErrorString(e));
     *out = static_cast<const float*>(m->h_frame);
+    return RT_OK;
+}
+
+/* the counters of the last counted render summed over the shards, the slowest shard's kernel time */
+int rt_get_stats_multi(rt_multi* m, rt_stats_t* out) {
+    if (!m || !out) return RT_ERR_INVALID_ARGUMENT;
+    rt_stats_t sum;
+    std::memset(&sum, 0, sizeof(sum));
+    for (size_t r = 0; r < m->ctx.size(); ++r) {
+        rt_stats_t s;
+        const int rc = rt_get_stats(m->ctx[r], &s);
+        if (rc != RT_OK) return multi_fail(m, rc, m->ctx[r]->error);
+        if (r == 0) sum = s;
+        else {
+            sum.rays_traced += s.rays_traced;
+            sum.rays_reference += s.rays_reference;
+            sum.hit_pixels += s.hit_pixels;
+            sum.object_tests += s.object_tests;
+            sum.local_rays += s.local_rays;
+            sum.last_kernel_ms = std::max(sum.last_kernel_ms, s.last_kernel_ms);
+            sum.rounds = std::max(sum.rounds, s.rounds);
+            sum.wavefront = sum.wavefront | s.wavefront;
+        }
+    }
+    *out = sum;
+    return RT_OK;
+}
+
+int rt_count_rays_multi(rt_multi* m) {
+    if (!m) return RT_ERR_INVALID_ARGUMENT;
+    for (rt_context* c : m->ctx) {
+        const int rc = rt_count_rays(c);
+        if (rc != RT_OK) return multi_fail(m, rc, c->error);
+    }
     return RT_OK;
 }
 

@@ -68,6 +68,7 @@ enum : uint32_t {
     RS_CUR = 6,                             // which queue pair that is
     RS_FINISH = 7,                          // 0: rounds go on, 1: the rest belongs to wf_finish, 2: nothing left
     RS_ROUNDS = 8,                          // rounds that had work (statistics)
+    RS_FRAME_STUCK = 9,                     // wf_frame: waves that gave up on a state in which nothing could move (a logic error: the host fails the frame)
     RS_WORDS = 16
 };
 
@@ -2155,30 +2156,27 @@ __global__ __launch_bounds__(256) void wf_finish(const WfParams wk) {
 // pixel (shade_and_reflect_kernel.cl:244-285). The round machine above cuts that loop at every ray and puts a device-wide
 // barrier there: 5 rounds x {two walks, wf_resume, wf_advance} = 21 launches per cfg4 frame, every persistent walk draining
 // from 54 to 0 live lanes before the next kernel may start (~0.15 ms per launch that no split of the frame over more GPUs
-// removes), and a memory-bound wf_resume that runs alone between issue-bound walks. Here a LANE keeps its
-// pixel from the primary hit to the final store:
-//   * a lane whose closest-hit walk has ended does its pixel's next step ITSELF the next time rays are handed out
-//     (frame_step: materialise the hit, test the last light's shadow ray on the spot through the light tile - the list
-//     wf_resume's last hits and wf_finish already walk in one thread, last_light_blocked - shade, accumulate, build the
-//     reflection ray, test it against the object it leaves) and walks on with the new ray; a lane whose pixel has been
-//     written takes the next pixel of its wave's run. No queue, no pixel state in HBM, no second ray kind in flight: the
-//     accumulators (absorbColor, absorptionPercent, reflectColor, bounces) live in 32 bytes of LDS per lane, the ray and
-//     its result in the walk's registers;
-//   * the walk is block_segment's, trip for trip (same blocks, same pre-tests, same parked exact tests, same order-free
-//     update), so (t, index) of every ray are the round machine's bits; the step calls the round machine's own device
-//     functions, so every colour is too;
-//   * what a step cannot finish in this form - the light loop's backward scan has to go on to an earlier light (stale
-//     specular: lit with nDotL <= 0) - is handed to the round machine: the pixel's state BEFORE the step is written in
-//     wf_resume's format (ray in slot 0, accumulators, phase PH_PRIMARY / PH_REFLECT) and the pixel appended to the next
-//     closest-hit queue; wf_finish (or, should there be many, further rounds) re-traces that ray and carries on.
+// removes), and a memory-bound wf_resume that runs alone between issue-bound walks. Here a pixel goes from
+// its primary hit to its final store inside ONE persistent launch, without ever meeting a barrier:
+//   * the waves of a workgroup take roles (below: "roles"): WALKERS trace closest-hit rays - block_segment's loop, trip for
+//     trip (same blocks, same pre-tests, same parked exact tests, same order-free update), so (t, index) of every ray are the
+//     round machine's bits - and a STEPPER runs the pixels' steps, a full wave of them at a time (frame_step: materialise the
+//     hit, build the reflection ray and test it against the object it leaves, test the light loop's shadow rays on the spot -
+//     the last light's through its light tile, the list wf_resume's last hits and wf_finish already walk in one thread - shade,
+//     accumulate, write the pixel or queue its reflection ray). The step calls the round machine's own device functions, so
+//     every colour is the round machine's too;
+//   * rays and pixel state travel between the two through rings in LDS: no queue and no pixel state in HBM, no second ray
+//     kind in flight (the shadow rays never leave the step);
+//   * primary rays keep their own first kernel (screen tiles: wave-uniform lists), whose (t, index) per work-item the stepper
+//     reads when it admits a pixel.
 // Used for shade_and_reflect frames through grid + block grid + block-form light tiles without triangles or always-tested
-// objects (launch: frame_kernel_applies); everything else keeps the rounds. Primary rays keep their own first kernel
-// (screen tiles: wave-uniform lists), whose (t, index) per work-item this kernel reads when it admits a pixel.
+// objects (launch: frame_kernel_applies); everything else keeps the rounds.
 #ifndef RT_FRAME_WAVES
-#define RT_FRAME_WAVES 4          // waves per SIMD the kernel is compiled for (128 registers: the step is wf_resume's arithmetic)
+#define RT_FRAME_WAVES 4          // waves per SIMD the kernel is compiled for. MEASURED (the block walk alone, occupancy forced by unused LDS,
+                                  // cfg4 frame): 6 waves 11.80 ms, 5: 12.23, 4: 12.24, 3: 13.47 - four cost the walk 7 %, three 26 %
 #endif
 #ifndef RT_FRAME_REFILL_MIN
-#define RT_FRAME_REFILL_MIN 16    // steps / admissions run once this many lanes have one to do (a step is ~800 instructions)
+#define RT_FRAME_REFILL_MIN 16    // a walker parks / takes rays once this many of its lanes are not walking (a ray's set-up is ~150 instructions)
 #endif
 struct FrameAcc {
     float abr, abg, abb, ap;      // absorbColor, absorptionPercent (shade_and_reflect_kernel.cl:255-257)
@@ -2186,75 +2184,171 @@ struct FrameAcc {
     uint32_t bounces;             // as the loop's unsigned counter AFTER its post-decrement
 };
 
-// shade()'s light loop for hit h where the LAST light decides the colour alone (resume_shadow's backward scan at its first
-// light, statement for statement; shade_last_light_inline has the same lines). False: the scan has to go on to an earlier light.
-template <bool FUSED>
-__device__ __forceinline__ bool shade_last_light_now(const WfParams& w, const HitRec& h, float& cr, float& cg, float& cb, float& absorb, uint32_t& tests) {
+// shade()'s light loop for hit h, shade_and_reflect's way (shade_last_light_wins, rt_device.h, statement for statement; the
+// round machine spreads the same loop over resume_shadow's visits): ambient and diffuse are the LAST light's, the specular
+// belongs to the last light that was either blocked or lit with nDotL > 0 - scan backwards and stop there. The last light's
+// shadow ray goes through its light tile (last_light_blocked), an earlier light's - the stale-specular case, a per cent of
+// the hits - through the fine grid in one thread (any_hit_grid, as wf_finish traces it where the block walk does not apply).
+template <bool FUSED, bool BLOCKS>
+__device__ __forceinline__ void shade_scan_now(const WfParams& w, const HitRec& h, float& cr, float& cg, float& cb, float& absorb, uint32_t& tests,
+                                               uint32_t& shadow_rays) {
     const Scene& S = w.rp.scene;
-    const uint32_t li = S.n_lights - 1u;
-    float nDotL, rDotV;
-    bool lit;
-    {
-        float nvx = h.nx, nvy = h.ny, nvz = h.nz;
-        normalize3_shading(S.fast_phong != 0u, nvx, nvy, nvz);
-        float vvx = -h.px, vvy = -h.py, vvz = -h.pz;
-        normalize3_shading(S.fast_phong != 0u, vvx, vvy, vvz);
-        LightGeom g;
-        light_geometry<FUSED>(S.lights[li], h, nvx, nvy, nvz, vvx, vvy, vvz, g, S.fast_phong != 0u);
-        nDotL = g.nDotL; rDotV = g.rDotV;
-        lit = !last_light_blocked<FUSED>(w, g.shadow, tests);
-    }
-    const LightRec L = S.lights[li];
     const ColdObject* co = S.cold + h.index;
-    const float4 amb = co->amb_absorb, dif = co->dif_shine, spec = co->spec_type;
-    float dr = 0.f, dg = 0.f, db = 0.f, sr = 0.f, sg = 0.f, sb = 0.f;
-    const float ar = amb.x * L.ambient.x, ag = amb.y * L.ambient.y, ab = amb.z * L.ambient.z;
-    if (lit) {
-        const float nd = __builtin_fmaxf(nDotL, 0.f);
-        dr = (dif.x * L.diffuse.x) * nd; dg = (dif.y * L.diffuse.y) * nd; db = (dif.z * L.diffuse.z) * nd;
-    }
+    float nvx = h.nx, nvy = h.ny, nvz = h.nz;
+    normalize3_shading(S.fast_phong != 0u, nvx, nvy, nvz);
+    float vvx = -h.px, vvy = -h.py, vvz = -h.pz;
+    normalize3_shading(S.fast_phong != 0u, vvx, vvy, vvz);
+    float sr = 0.f, sg = 0.f, sb = 0.f;
+    float dr = 0.f, dg = 0.f, db = 0.f;
+    float ar = 0.f, ag = 0.f, ab = 0.f;
     bool need_specular = true;
-    if (!lit) {
-        need_specular = false;
-    } else if (nDotL > 0) {
-        const float pw = specular_power(rDotV, dif.w, S.fast_phong != 0u);
-        sr = (spec.x * L.specular.x) * pw; sg = (spec.y * L.specular.y) * pw; sb = (spec.z * L.specular.z) * pw;
-        need_specular = false;
+    for (uint32_t li = S.n_lights; li-- > 0 && need_specular;) {
+        const LightRec L = S.lights[li];
+        LightGeom g;
+        light_geometry<FUSED>(L, h, nvx, nvy, nvz, vvx, vvy, vvz, g, S.fast_phong != 0u);
+        shadow_rays += 1u;
+        bool blocked;
+        if (li == w.ltiles.light) {
+            blocked = last_light_blocked<FUSED>(w, g.shadow, tests);
+        } else {
+            // a light without tiles: one thread through the block grid, or - rays that walk is not made for, and always in wf_frame's
+            // stepper (BLOCKS = false), where the second walk inlined cost every step 56 spilled registers, as a real call 151 -
+            // through the fine grid: wf_finish's pair of walks, same answer either way
+            bool walked = false;
+            blocked = false;
+            if (BLOCKS) {
+                Ray r1 = g.shadow;
+                r1.sw = 1.0f; r1.dw = 0.0f;
+                blocked = any_hit_blocks<FUSED>(w.bgrid, w.grid, S.hot, r1, walked, tests);
+            }
+            if (!walked) blocked = any_hit_grid<FUSED>(w.grid, S, g.shadow, tests);
+        }
+        const bool lit = !blocked;
+        if (li == S.n_lights - 1u) {
+            const float4 amb = co->amb_absorb, dif = co->dif_shine;
+            ar = amb.x * L.ambient.x; ag = amb.y * L.ambient.y; ab = amb.z * L.ambient.z;
+            if (lit) {
+                const float nd = __builtin_fmaxf(g.nDotL, 0.f);
+                dr = (dif.x * L.diffuse.x) * nd; dg = (dif.y * L.diffuse.y) * nd; db = (dif.z * L.diffuse.z) * nd;
+            }
+        }
+        if (!lit) {
+            need_specular = false;  // zeroed here, nothing later re-assigns it
+        } else if (g.nDotL > 0) {
+            const float4 dif = co->dif_shine, spec = co->spec_type;
+            const float pw = specular_power(g.rDotV, dif.w, S.fast_phong != 0u);
+            sr = (spec.x * L.specular.x) * pw; sg = (spec.y * L.specular.y) * pw; sb = (spec.z * L.specular.z) * pw;
+            need_specular = false;
+        }
+        // lit with nDotL <= 0: the specular of an earlier light is still live - keep scanning
     }
-    if (need_specular && li > 0u) return false;
     cr = (ar + dr) + sr; cg = (ag + dg) + sg; cb = (ab + db) + sb;
-    absorb = amb.w;
-    return true;
+    absorb = co->amb_absorb.w;
 }
 
-// the pixel as the round machine wants to find it in a closest-hit queue: its ray not traced yet, its state in HBM
-__device__ __forceinline__ void frame_hand_over(const WfParams& w, uint32_t pix, bool primary, Ray ray, const FrameAcc& a) {
-    ray.sw = 1.0f;
-    ray.dw = __uint_as_float(0xffffffffu);  // no note for the walk: it tests the object the ray leaves like any other (begin_shade_lit)
-    store_ray(w, pix, ray, kSlotClosest);
-    if (primary) {
-        store_block(w, F_NX, pix, make_float4(0.f, 0.f, 0.f, __uint_as_float(PH_PRIMARY)));
-    } else {
-        store_block(w, F_ABR, pix, make_float4(a.abr, a.abg, a.abb, a.ap));
-        U(w, F_BOUNCES, pix) = a.bounces;
-        store_block(w, F_RR, pix, make_float4(a.rr, a.rg, a.rb, 0.f));
-        store_block(w, F_NX, pix, make_float4(0.f, 0.f, 0.f, __uint_as_float(PH_REFLECT)));
+// A wave's two rings, in LDS (nobody but the wave touches them: no barrier, no atomics - the counters are wave-uniform
+// registers). A ray whose walk has ended is PARKED in `due` by its lane, which then takes the next ray waiting in `rdy`;
+// once enough pixels are due, the WHOLE wave runs their steps - one pixel per lane, every lane busy - and what goes on is
+// queued in `rdy`. Round 4's first form let a lane step its own pixel at hand-out time: ~800 instructions at 10-16 of 64
+// lanes, twice per hand-out - 24.3 ms per cfg4 frame against the round machine's 11.9.
+#ifndef RT_FRAME_RING
+#define RT_FRAME_RING 96   // entries per ring: 132 bytes x entries x walkers per workgroup x workgroups per CU <= 160 KB
+#endif
+constexpr uint32_t kRing = RT_FRAME_RING;
+static_assert(kRing >= 64, "a full wave of steps");
+// Pixels a wave has in flight (walking + due + waiting). With at most 64 + kRing of them no state exists in which nothing can
+// move: all 64 lanes holding a finished ray they cannot park (due full) AND rays waiting in rdy would be 65 + kRing pixels.
+constexpr uint32_t kPixelsInFlight = 64u + kRing;
+struct FrameRings {
+    float4 due[4][kRing];      // {start, T}, {direction, index}, {absorbColor, absorptionPercent}, {reflectColor, bounces}
+    uint32_t due_pix[kRing];
+    float4 rdy[4][kRing];      // {start, note}, {direction, pixel}, accumulators as above
+};
+static_assert(sizeof(FrameRings) == 132u * kRing, "layout");
+
+// Where a step finds its pixel and leaves what goes on: wf_frame's LDS rings (RingIO) or the round machine's pixel state in
+// HBM (StateIO, wf_step). traced(): the ray that came back, its result and the work-item; ap_bounces(): absorptionPercent and
+// bounces before this hit; acc(): all accumulators; put_ray() / put_acc(): the reflection ray (with the note for the walk) and
+// the accumulators of a pixel that goes on.
+struct RingIO {
+    FrameRings& R;
+    uint32_t dslot, pslot;
+    __device__ __forceinline__ void traced(Ray& ray, float& T, int& idx, uint32_t& pix) const {
+        const float4 e0 = R.due[0][dslot], e1 = R.due[1][dslot];
+        pix = R.due_pix[dslot];
+        ray.sx = e0.x; ray.sy = e0.y; ray.sz = e0.z; T = e0.w;
+        ray.dx = e1.x; ray.dy = e1.y; ray.dz = e1.z; idx = (int)__float_as_uint(e1.w);
     }
-    push(w.q_closest, &w.counts[RS_NEXT_CLOSEST], pix);
-}
+    __device__ __forceinline__ void ap_bounces(float& ap, uint32_t& bounces) const { ap = R.due[2][dslot].w; bounces = __float_as_uint(R.due[3][dslot].w); }
+    __device__ __forceinline__ void acc(FrameAcc& a) const {
+        const float4 e2 = R.due[2][dslot], e3 = R.due[3][dslot];
+        a.abr = e2.x; a.abg = e2.y; a.abb = e2.z; a.ap = e2.w;
+        a.rr = e3.x; a.rg = e3.y; a.rb = e3.z; a.bounces = __float_as_uint(e3.w);
+    }
+    __device__ __forceinline__ void put_ray(const Ray& nr, uint32_t note, uint32_t pix) const {
+        R.rdy[0][pslot] = make_float4(nr.sx, nr.sy, nr.sz, __uint_as_float(note));
+        R.rdy[1][pslot] = make_float4(nr.dx, nr.dy, nr.dz, __uint_as_float(pix));
+    }
+    __device__ __forceinline__ void put_acc(const FrameAcc& a) const {
+        R.rdy[2][pslot] = make_float4(a.abr, a.abg, a.abb, a.ap);
+        R.rdy[3][pslot] = make_float4(a.rr, a.rg, a.rb, __uint_as_float(a.bounces));
+    }
+};
+struct StateIO {   // ray slot 0, F_RES_T / F_RES_I, the F_ABR block, the F_RR block with the bounces in its spare word
+    const WfParams& w;
+    uint32_t pix0;
+    __device__ __forceinline__ void traced(Ray& ray, float& T, int& idx, uint32_t& pix) const {
+        pix = pix0;
+        load_closest_result(w, pix0, T, idx);
+        const Ray r = load_ray(w, pix0, kSlotClosest);
+        ray.sx = r.sx; ray.sy = r.sy; ray.sz = r.sz; ray.dx = r.dx; ray.dy = r.dy; ray.dz = r.dz;  // (w = 1 / 0: the slot carried the walk's note)
+    }
+    __device__ __forceinline__ void ap_bounces(float& ap, uint32_t& bounces) const { ap = F(w, F_AP, pix0); bounces = U(w, F_SPARE, pix0); }
+    __device__ __forceinline__ void acc(FrameAcc& a) const {
+        const float4 e2 = load_block(w, F_ABR, pix0), e3 = load_block(w, F_RR, pix0);
+        a.abr = e2.x; a.abg = e2.y; a.abb = e2.z; a.ap = e2.w;
+        a.rr = e3.x; a.rg = e3.y; a.rb = e3.z; a.bounces = __float_as_uint(e3.w);
+    }
+    __device__ __forceinline__ void put_ray(const Ray& nr, uint32_t note, uint32_t) const {
+        Ray r = nr;
+        r.sw = 1.0f; r.dw = __uint_as_float(note);
+        store_ray(w, pix0, r, kSlotClosest);
+    }
+    __device__ __forceinline__ void put_acc(const FrameAcc& a) const {
+        store_block(w, F_ABR, pix0, make_float4(a.abr, a.abg, a.abb, a.ap));
+        store_block(w, F_RR, pix0, make_float4(a.rr, a.rg, a.rb, __uint_as_float(a.bounces)));
+    }
+};
 
-// One step of a pixel: its closest-hit ray `ray` came back with (T, idx). True: the pixel goes on with the reflection ray now
-// in `ray` (`note` = the object it leaves, already tested, or ~0). False: the pixel has been written - or handed over.
-template <bool FUSED>
-__device__ __forceinline__ bool frame_step(const WfParams& w, uint32_t pix, bool primary, Ray& ray, uint32_t& note, float T, int idx,
-                                           FrameAcc& a, Ctx& cnt) {
+// One step of a pixel = shade_and_reflect's loop body (:253-284) for a pixel whose closest-hit ray came back with (T, idx):
+// either a ray `io` knows, or - a NEW pixel, `primary` - work-item `pix` with the first kernel's result. True: the pixel goes
+// on; its reflection ray, the note for the walk (the object it leaves, already tested, or ~0) and its accumulators have been
+// put down through `io`. False: the pixel has been written.
+// In wf_frame the step runs next to walks on a 128-register budget, and what is kept in registers across its heavy part (the
+// shadow test) decides how much goes to scratch (a first ring version spilled ~70 registers per lane and step: 18 GB of scratch
+// writes per frame). So `io` doubles as the step's memory: the accumulators stay where they are until the colour is known, and
+// the reflection ray is built and tested against its own object right after materialise() - while the object's rows are in
+// registers - and put down before the shading starts (whether the loop will cast it depends on the loop state, not on the
+// colour: begin_shade_lit's `sends`).
+template <bool FUSED, bool BLOCKS, typename IO>
+__device__ __forceinline__ bool frame_step(const WfParams& w, const IO& io, bool primary, uint32_t pix, Ctx& cnt) {
     const RenderParams& p = w.rp;
     const Scene& S = p.scene;
+    float4* out = reinterpret_cast<float4*>(p.out);
+    Ray ray = {0.f, 0.f, 0.f, 1.0f, 0.f, 0.f, 0.f, 0.0f};  // (what every ray of a grid-able frame carries: rt_create checks)
+    float T;
+    int idx;
+    if (!primary) {
+        io.traced(ray, T, idx, pix);
+    } else {
+        load_closest_result(w, pix, T, idx);   // the first kernel's (t, index) of this work-item's primary ray
+        const Ray pr = closest_ray(w, pix, true);
+        ray.sx = pr.sx; ray.sy = pr.sy; ray.sz = pr.sz; ray.dx = pr.dx; ray.dy = pr.dy; ray.dz = pr.dz;
+    }
     if (T == kMaxFloat) patch_nan_result(w, ray, T, idx);
     const bool hit = !(T == kMaxFloat);
     const uint64_t px = pixel_of(p, pix);
-    float4* out = reinterpret_cast<float4*>(p.out);
-    auto finish = [&]() {  // the tail of shade_and_reflect (:281-284): finish_reflect without the phase word
+    auto finish = [&](const FrameAcc& a) {  // the tail of shade_and_reflect (:281-284): finish_reflect without the phase word
         float abr = a.abr, abg = a.abg, abb = a.abb;
         if (a.bounces == 0u && a.ap < 1.f) {
             const float wgt = 1.f - a.ap;
@@ -2265,31 +2359,59 @@ __device__ __forceinline__ bool frame_step(const WfParams& w, uint32_t pix, bool
     if (primary) {
         if (p.aux_t) p.aux_t[px] = T;
         if (p.aux_index) p.aux_index[px] = hit ? idx : -1;
-        if (!hit) { cnt.traced += 1; cnt.reference += 1; out[px] = make_float4(0.f, 0.f, 0.f, 1.0f); return false; }
+        cnt.traced += 1; cnt.reference += 1; cnt.hits += hit ? 1 : 0;
+        if (!hit) { out[px] = make_float4(0.f, 0.f, 0.f, 1.0f); return false; }
     } else if (!hit) {  // raycast() false (:268)
-        finish();
+        FrameAcc a;
+        io.acc(a);
+        finish(a);
         return false;
     }
-    HitRec h;
-    ObjRows rows;
-    float absorb_h;
-    materialise<FUSED>(S.objrec, S.cold, idx, T, ray, h, S.affine != 0u, &rows, &absorb_h);
+    float hpx, hpy, hpz, hnx, hny, hnz, absorb_h;
+    int hindex;
+    bool sends;
+    {
+        HitRec h;
+        ObjRows rows;
+        materialise<FUSED>(S.objrec, S.cold, idx, T, ray, h, S.affine != 0u, &rows, &absorb_h);
+        hpx = h.px; hpy = h.py; hpz = h.pz; hnx = h.nx; hny = h.ny; hnz = h.nz; hindex = h.index;
+        // Will the loop cast this hit's reflection ray? (the statements below are shade_done's and loop_step's, ahead of time)
+        uint32_t bounces_in = p.max_bounces;
+        float ap_after = absorb_h;
+        if (!primary) {
+            float ap_old;
+            io.ap_bounces(ap_old, bounces_in);
+            const float ra = (1.f - ap_old) * absorb_h;
+            ap_after = ap_old + ra;
+        }
+        sends = bounces_in > 0u && ap_after <= 0.999f;
+        if (sends) {
+            Ray nr;
+            reflection_ray<FUSED>(h, nr);
+            float t_self;
+            bool sphere_self;
+            const bool self_hit = rows_candidate<FUSED, true>(rows, nr, t_self, sphere_self);  // begin_shade_lit: the ray's own object, tested here
+            io.put_ray(nr, self_hit ? 0xffffffffu : (uint32_t)h.index, pix);
+        }
+    }
     float cr, cg, cb, absorb;
-    uint32_t tests = 0;
-    if (!shade_last_light_now<FUSED>(w, h, cr, cg, cb, absorb, tests)) {
-        frame_hand_over(w, pix, primary, ray, a);  // (nothing of this step has been counted or written)
-        return false;
+    uint32_t tests = 0, shadow_rays = 0;
+    {
+        HitRec h;
+        h.px = hpx; h.py = hpy; h.pz = hpz; h.pw = 1.0f; h.nx = hnx; h.ny = hny; h.nz = hnz; h.rx = 0.f; h.ry = 0.f; h.rz = 0.f; h.index = hindex;
+        shade_scan_now<FUSED, BLOCKS>(w, h, cr, cg, cb, absorb, tests, shadow_rays);
     }
-    if (primary) { cnt.traced += 1; cnt.reference += 1; cnt.hits += 1; }
-    cnt.traced += 1;               // the shadow ray just tested
+    cnt.traced += shadow_rays;     // the shadow rays just tested
     cnt.reference += S.n_lights;   // the light loop's rays (begin_shade_lit)
     cnt.tests += tests;
+    FrameAcc a;
     if (primary) {  // absorbColor = hit.mat.absorption * shade(hit) (:255-256); bounces = MAX_BOUNCES (:258)
         a.ap = absorb;
         a.abr = cr * a.ap; a.abg = cg * a.ap; a.abb = cb * a.ap;
         a.rr = 0.f; a.rg = 0.f; a.rb = 0.f;
         a.bounces = p.max_bounces;
     } else {        // (:270-274)
+        io.acc(a);
         const float ra = (1.f - a.ap) * absorb;
         a.abr = fma_<FUSED>(ra, cr, a.abr); a.abg = fma_<FUSED>(ra, cg, a.abg); a.abb = fma_<FUSED>(ra, cb, a.abb);
         a.ap = a.ap + ra;
@@ -2298,39 +2420,55 @@ __device__ __forceinline__ bool frame_step(const WfParams& w, uint32_t pix, bool
     // top of `while (bounces-- > 0 && raycast(...) && absorptionPercent <= 0.999f)` (:268), as loop_step
     const uint32_t before = a.bounces;
     a.bounces = before - 1u;
-    if (!(before > 0u)) { finish(); return false; }
+    if (!(before > 0u)) { finish(a); return false; }
     cnt.reference += 1;
-    if (!(a.ap <= 0.999f)) { finish(); return false; }  // the reference casts this ray but never reads its result
-    reflection_ray<FUSED>(h, ray);
-    float t_self;
-    bool sphere_self;
-    const bool self_hit = rows_candidate<FUSED, true>(rows, ray, t_self, sphere_self);  // begin_shade_lit: the ray's own object, tested here
-    note = self_hit ? 0xffffffffu : (uint32_t)h.index;
+    if (!(a.ap <= 0.999f)) { finish(a); return false; }  // the reference casts this ray but never reads its result
+    // (`sends` said so - same inputs, same arithmetic - and the ray has been put down already)
+    io.put_acc(a);
     cnt.traced += 1;
-    return true;
+    return sends;
 }
 
+// ---- roles ----
+// A step needs ~125 registers (it is wf_resume's arithmetic), a walking lane ~45 that stay live across it: a wave that did both
+// had 189 to hold in 128 and spilled 70-120 of them per lane and step (18 GB of scratch writes per frame, round 4's second
+// form: 15.8 ms). So the waves of a workgroup take ROLES: wave 0 is the STEPPER, waves 1-3 are WALKERS. Each walker owns a
+// `due` and a `rdy` ring in LDS (FrameRings, single producer / single consumer each: the walker parks finished rays in `due`
+// and takes rays from `rdy`, the stepper does the opposite), four counters say how far either side has got (FrameCtl; written
+// with release, read with acquire at workgroup scope - LDS is one in-order memory per CU, the fences are for the compiler).
+// A pixel stays with its walker from admission to the final store; the stepper admits new pixels (it draws the runs) while a
+// walker has fewer than kPixelsInFlight of them. max(walk, step) registers instead of their sum; nothing ever waits on a
+// device-wide barrier, and nothing but the framebuffer, the first kernel's results and the scene tables touches memory.
+struct FrameCtl {
+    uint32_t due_tail;   // walker: rays parked in `due` so far          (slot = count mod kRing; all counts only grow)
+    uint32_t due_head;   // stepper: ... of which it has consumed
+    uint32_t rdy_tail;   // stepper: rays queued in `rdy` so far
+    uint32_t rdy_head;   // walker: ... of which it has taken
+    uint32_t starving;   // walker: nothing walks and nothing waits (the stepper then steps whatever is due, however little)
+    uint32_t quit;       // stepper: this walker's part of the frame is finished
+    uint32_t pad[2];
+};
+constexpr uint32_t kFrameWalkers = 3;   // walker waves per workgroup (+ one stepper)
+static_assert(132u * kRing * kFrameWalkers + (sizeof(FrameCtl) + 32u) * kFrameWalkers <= 40u * 1024u, "four workgroups per CU");
+
+__device__ __forceinline__ uint32_t ctl_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void ctl_store(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+constexpr uint32_t kFrameSpinLimit = 1u << 22;  // idle polls in a row before a wave gives up (a logic error's cost bound; each poll sleeps)
+
+// A WALKER: block_segment's loop, fed from its `rdy` ring instead of a queue, parking results in its `due` ring.
 template <bool FUSED, bool COUNT>
-__device__ __forceinline__ void frame_segment(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue, uint32_t wave,
-                                              uint32_t n_waves, uint32_t* __restrict__ run_ctr, float4* __restrict__ s_acc, Ctx& cnt,
-                                              unsigned long long& tested) {
+__device__ __forceinline__ void frame_walker(const WfParams& w, FrameRings& R, FrameCtl& C, unsigned long long& tested) {
     const uint32_t lane = threadIdx.x & 63u;
-    RunCursor rc;
-    if (!rc.begin(n_queue, wave, n_waves, run_ctr, lane)) return;
-    uint32_t& next = rc.next;
-    const uint32_t& seg_end = rc.seg_end;
-    bool more = rc.dynamic;
     const GridDesc& g = w.grid;
     const BlockGrid& bg = w.bgrid;
     const HotObject* __restrict__ hot = w.rp.scene.hot;
     const float wnx_f = (float)bg.wnx, wny_f = (float)bg.wny;
-    float4* my_acc = s_acc + 2u * threadIdx.x;  // this lane's FrameAcc between steps (nobody else reads it: no barrier anywhere)
 
     constexpr uint32_t kAlive = 1u;    // the lane holds a ray that is being walked ...
     constexpr uint32_t kOver = 2u;     // ... whose walk has ended (it may still wait for its parked exact test)
     constexpr uint32_t kPend = 4u;     // a candidate is parked for the next round of exact tests (pend_k)
     constexpr uint32_t kSphere = 8u;   // the current best hit is a sphere (closest_take's tie rule)
-    constexpr uint32_t kDone = 16u;    // the lane holds a ray whose result (T, idx) is final: its pixel's step is due
+    constexpr uint32_t kDone = 16u;    // the lane holds a ray whose result (T, idx) is final and not yet parked in `due`
     uint32_t fl = 0u;
     uint32_t pix = 0;
     float rsx = 0.f, rsy = 0.f, rsz = 0.f, rdx = 0.f, rdy = 0.f, rdz = 0.f, dd = 0.f;
@@ -2340,99 +2478,125 @@ __device__ __forceinline__ void frame_segment(const WfParams& w, const uint32_t*
     float T = kMaxFloat, limit = 0.f, t_stop = 0.f, slack = 0.f;
     int idx = -1;
     uint32_t pend_k = 0, done_k = 0xffffffffu;
+    float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = make_float4(0.f, 0.f, 0.f, 0.f);  // the pixel's accumulators ride along
+    // this side's cursors (wave-uniform): counts as published in C, slots wrapped
+    uint32_t due_tail = 0, due_slot = 0, rdy_head = 0, rdy_slot = 0;
+    uint32_t spins = 0;
+    bool said_starving = false;
+    unsigned long long s_rays = 0, s_trips = 0, s_live = 0, s_flush = 0, s_refill = 0, s_starved = 0, s_stalled = 0;  // COUNT only
 
     for (;;) {
-        if (next >= seg_end && more) more = rc.grab(n_queue, run_ctr, lane);  // on to another run, if any is left
-        // ---- steps of the pixels whose ray has come back, new pixels for the lanes whose pixel has been written ----
-        const unsigned long long idle = __ballot((fl & kAlive) == 0u);
-        const unsigned long long due = __ballot((fl & kDone) != 0u);
-        const uint32_t n_due = (uint32_t)__popcll(due), n_empty = (uint32_t)__popcll(idle) - n_due;
-        const uint32_t left = next < seg_end ? seg_end - next : 0u;
-        const uint32_t ready = n_due + (n_empty < left ? n_empty : left);
-        if (ready != 0u && (ready >= (uint32_t)RT_FRAME_REFILL_MIN || idle == ~0ull)) {
-#pragma nounroll
-            for (int pass = 0; pass < 2; ++pass) {
-                // pass 0: the lanes whose ray has come back; pass 1: the lanes without a pixel (those of pass 0 whose pixel ended included)
-                bool run = false, primary = false;
-                if (pass == 0) {
-                    run = (fl & kDone) != 0u;
-                } else {
-                    const bool empty = (fl & (kAlive | kDone)) == 0u;
-                    const unsigned long long em = __ballot(empty);
-                    const uint32_t mine = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
-                    if (empty && mine < seg_end) {
-                        const uint32_t entry = w.identity_queue ? mine : queue[mine];
-                        pix = w.identity_queue ? mine : (entry & kQueuePixel);
-                        load_closest_result(w, pix, T, idx);   // the first kernel's (t, index) of this work-item's primary ray
-                        const Ray pr = closest_ray(w, pix, true);
-                        rsx = pr.sx; rsy = pr.sy; rsz = pr.sz; rdx = pr.dx; rdy = pr.dy; rdz = pr.dz;
-                        run = true;
-                        primary = true;
-                    }
-                    const uint32_t n_em = (uint32_t)__popcll(em), room = next < seg_end ? seg_end - next : 0u;
-                    next += n_em < room ? n_em : room;
-                }
-                if (__ballot(run) == 0ull) continue;
-                if (run) {
-                    Ray ray = {rsx, rsy, rsz, 1.0f, rdx, rdy, rdz, 0.0f};  // (what every ray of a grid-able frame carries: rt_create checks)
-                    FrameAcc a;
-                    if (!primary) {
-                        const float4 a0 = my_acc[0], a1 = my_acc[1];
-                        a.abr = a0.x; a.abg = a0.y; a.abb = a0.z; a.ap = a0.w;
-                        a.rr = a1.x; a.rg = a1.y; a.rb = a1.z; a.bounces = __float_as_uint(a1.w);
-                    } else {
-                        a = FrameAcc{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0u};
-                    }
-                    uint32_t note = 0xffffffffu;
-                    const bool goes_on = frame_step<FUSED>(w, pix, primary, ray, note, T, idx, a, cnt);
+        // ---- hand-out: finished rays are parked, lanes without a ray take the next one that waits ----
+        const unsigned long long walking_m = __ballot((fl & kAlive) != 0u);
+        if (64u - (uint32_t)__popcll(walking_m) >= (uint32_t)RT_FRAME_REFILL_MIN) {
+            const bool fin = (fl & kDone) != 0u;
+            const unsigned long long fm = __ballot(fin);
+            if (fm != 0ull) {
+                const uint32_t room = kRing - (due_tail - ctl_load(&C.due_head));
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+                if (COUNT && lane == 0u) { ++s_refill; s_stalled += (uint32_t)__popcll(fm) > room ? (uint32_t)__popcll(fm) - room : 0u; }
+                if (fin && rank < room) {
+                    uint32_t slot = due_slot + rank;
+                    slot -= slot >= kRing ? kRing : 0u;
+                    R.due[0][slot] = make_float4(rsx, rsy, rsz, T);
+                    R.due[1][slot] = make_float4(rdx, rdy, rdz, __uint_as_float((uint32_t)idx));
+                    R.due[2][slot] = acc0;
+                    R.due[3][slot] = acc1;
+                    R.due_pix[slot] = pix;
                     fl = 0u;
-                    if (goes_on) {
-                        my_acc[0] = make_float4(a.abr, a.abg, a.abb, a.ap);
-                        my_acc[1] = make_float4(a.rr, a.rg, a.rb, __uint_as_float(a.bounces));
-                        // ---- the new ray's walk (block_segment's hand-out) ----
-                        rsx = ray.sx; rsy = ray.sy; rsz = ray.sz; rdx = ray.dx; rdy = ray.dy; rdz = ray.dz;
-                        ray.sw = 1.0f; ray.dw = 0.0f;
-                        T = kMaxFloat; idx = -1;
-                        bool cur_sphere = false;
-                        done_k = note;
-                        dd = rdx * rdx + rdy * rdy + rdz * rdz;
-                        slack = dd > 0.f ? kWalkSlackCells * bg.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
-                        bool start = false, brute = false;
-                        const Walk w0 = walk_begin(bg, ray, 3.0e38f);  // (a ray with a NaN in it: not alive)
-                        if (w0.alive) {
-                            const float dmin = __builtin_fminf(__builtin_fminf(w0.dtx, w0.dty), w0.dtz);
-                            const bool tame = dd > 1.0e-30f && dd < 1.0e30f && w0.t_enter <= 4096.f * dmin;
-                            brute = !tame;
-                            start = tame;
-                            fx = (float)(w0.ix + (int)kBlockBorder); fy = (float)(w0.iy + (int)kBlockBorder); fz = (float)(w0.iz + (int)kBlockBorder);
-                            cur = ((uint32_t)(w0.iz + (int)kBlockBorder) * bg.wny + (uint32_t)(w0.iy + (int)kBlockBorder)) * bg.wnx + (uint32_t)(w0.ix + (int)kBlockBorder);
-                            tx = w0.tx; ty = w0.ty; tz = w0.tz; dtx = w0.dtx; dty = w0.dty; dtz = w0.dtz;
-                            t_stop = __builtin_fminf(w0.t_exit + 0.25f * dmin, 3.0e38f);
-                        }
-                        if (brute) {  // a ray the walk is not made for (a direction of absurd magnitude) tests every object, here and now
-                            for (uint32_t k = 0; k < w.rp.scene.n_objs; ++k) {
-                                float t;
-                                bool sphere;
-                                const bool cand = lane_candidate<FUSED, true, false>(hot + k, ray, t, sphere);
-                                if (COUNT) ++tested;
-                                if (cand) closest_take(t, (int)k, sphere, T, idx, cur_sphere);
-                            }
-                        }
-                        limit = __builtin_fminf(T + slack, t_stop);
-                        // no cell to look at, or everything tested already: the result is final, the next step is due
-                        fl = start ? (kAlive | (cur_sphere ? kSphere : 0u)) : kDone;
+                }
+                const uint32_t n_fin = (uint32_t)__popcll(fm);
+                const uint32_t parked = n_fin < room ? n_fin : room;
+                if (parked != 0u) {
+                    due_tail += parked;
+                    due_slot += parked;
+                    due_slot -= due_slot >= kRing ? kRing : 0u;
+                    ctl_store(&C.due_tail, due_tail);  // (release: the entries above are in LDS before the count says so)
+                }
+            }
+            const bool empty = (fl & (kAlive | kDone)) == 0u;
+            const unsigned long long em = __ballot(empty);
+            if (em != 0ull) {
+                const uint32_t waiting = ctl_load(&C.rdy_tail) - rdy_head;
+                const uint32_t n_em = (uint32_t)__popcll(em);
+                const uint32_t taken = n_em < waiting ? n_em : waiting;
+                const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(em >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)em, 0u));
+                if (empty && k < taken) {
+                    uint32_t slot = rdy_slot + k;
+                    slot -= slot >= kRing ? kRing : 0u;
+                    const float4 a0 = R.rdy[0][slot], a1 = R.rdy[1][slot];
+                    acc0 = R.rdy[2][slot];
+                    acc1 = R.rdy[3][slot];
+                    rsx = a0.x; rsy = a0.y; rsz = a0.z; rdx = a1.x; rdy = a1.y; rdz = a1.z;
+                    pix = __float_as_uint(a1.w);
+                    if (COUNT) ++s_rays;
+                    // ---- the ray's walk (block_segment's hand-out) ----
+                    const Ray ray = {rsx, rsy, rsz, 1.0f, rdx, rdy, rdz, 0.0f};  // (what every ray of a grid-able frame carries: rt_create checks)
+                    T = kMaxFloat; idx = -1;
+                    bool cur_sphere = false;
+                    done_k = __float_as_uint(a0.w);  // frame_step's note: the object the ray leaves has had its exact test
+                    dd = rdx * rdx + rdy * rdy + rdz * rdz;
+                    slack = dd > 0.f ? kWalkSlackCells * bg.cell * __builtin_amdgcn_rsqf(dd) * 1.0001f : 3.0e38f;
+                    bool start = false, brute = false;
+                    const Walk w0 = walk_begin(bg, ray, 3.0e38f);  // (a ray with a NaN in it: not alive)
+                    if (w0.alive) {
+                        const float dmin = __builtin_fminf(__builtin_fminf(w0.dtx, w0.dty), w0.dtz);
+                        const bool tame = dd > 1.0e-30f && dd < 1.0e30f && w0.t_enter <= 4096.f * dmin;
+                        brute = !tame;
+                        start = tame;
+                        fx = (float)(w0.ix + (int)kBlockBorder); fy = (float)(w0.iy + (int)kBlockBorder); fz = (float)(w0.iz + (int)kBlockBorder);
+                        cur = ((uint32_t)(w0.iz + (int)kBlockBorder) * bg.wny + (uint32_t)(w0.iy + (int)kBlockBorder)) * bg.wnx + (uint32_t)(w0.ix + (int)kBlockBorder);
+                        tx = w0.tx; ty = w0.ty; tz = w0.tz; dtx = w0.dtx; dty = w0.dty; dtz = w0.dtz;
+                        t_stop = __builtin_fminf(w0.t_exit + 0.25f * dmin, 3.0e38f);
                     }
+                    if (brute) {  // a ray the walk is not made for (a direction of absurd magnitude) tests every object, here and now
+                        for (uint32_t k2 = 0; k2 < w.rp.scene.n_objs; ++k2) {
+                            float t;
+                            bool sphere;
+                            const bool cand = lane_candidate<FUSED, true, false>(hot + k2, ray, t, sphere);
+                            if (COUNT) ++tested;
+                            if (cand) closest_take(t, (int)k2, sphere, T, idx, cur_sphere);
+                        }
+                    }
+                    limit = __builtin_fminf(T + slack, t_stop);
+                    // no cell to look at, or everything tested already: the result is final
+                    fl = start ? (kAlive | (cur_sphere ? kSphere : 0u)) : kDone;
+                }
+                if (taken != 0u) {
+                    rdy_head += taken;
+                    rdy_slot += taken;
+                    rdy_slot -= rdy_slot >= kRing ? kRing : 0u;
+                    ctl_store(&C.rdy_head, rdy_head);  // (release: the entries have been read before the slots are given back)
                 }
             }
         }
         const unsigned long long live = __ballot((fl & kAlive) != 0u);
         if (live == 0ull) {
-            if (__ballot((fl & kDone) != 0u) == 0ull && next >= seg_end && !more) break;
+            // nothing to walk: wait for the stepper (more rays, room in `due`, or the end of this walker's part of the frame)
+            const bool holding = __ballot((fl & kDone) != 0u) != 0ull;
+            if (!holding && ctl_load(&C.quit) != 0u && ctl_load(&C.rdy_tail) == rdy_head) break;
+            if (!holding && !said_starving) { ctl_store(&C.starving, 1u); said_starving = true; }
+            if (COUNT && lane == 0u) ++s_starved;
+            if (++spins > kFrameSpinLimit) { if (lane == 0u) atomicAdd(&w.counts[RS_FRAME_STUCK], 1u); break; }
+            __builtin_amdgcn_s_sleep(8);
             continue;
         }
+        if (said_starving) { ctl_store(&C.starving, 0u); said_starving = false; }
+#ifndef RT_FRAME_YIELD_LIVE
+#define RT_FRAME_YIELD_LIVE 0
+#endif
+        if (RT_FRAME_YIELD_LIVE != 0 && (uint32_t)__popcll(live) < (uint32_t)RT_FRAME_YIELD_LIVE && ctl_load(&C.due_head) != due_tail && spins < 64u) {
+            // few lanes walking, nothing waiting, and the stepper has not yet got to what this wave has parked: a trip costs the
+            // same ~370 instructions with 20 lanes as with 60 - leave the issue slots to the stepper for a moment (bounded: 64 naps)
+            ++spins;
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        spins = 0u;
         // ---- one trip: the block under the cursor (block_segment, trip for trip) ----
         const bool walking = (fl & (kAlive | kOver)) == kAlive;
         uint32_t stalled = 0u;
+        if (COUNT && lane == 0u) { ++s_trips; s_live += (unsigned long long)__popcll(live); }
         if (walking) {
             const uint32_t b = cur & 0xffffffu, pos = cur >> 24;
             const uint4 q0 = table_at(bg.blocks, 2u * b);
@@ -2499,6 +2663,7 @@ __device__ __forceinline__ void frame_segment(const WfParams& w, const uint32_t*
             const unsigned long long stuck = __ballot((fl & kPend) != 0u && (stalled != 0u || (fl & kOver) != 0u));
             const uint32_t n_live = (uint32_t)__popcll(live);
             if ((uint32_t)__popcll(pending) >= (uint32_t)RT_WALK3_DEFER_PENDING || ((uint32_t)__popcll(stuck) << RT_WALK3_STUCK_SHIFT) >= n_live) {
+                if (COUNT && lane == 0u) ++s_flush;
                 if ((fl & kPend) != 0u) {
                     float t;
                     bool sphere;
@@ -2515,8 +2680,130 @@ __device__ __forceinline__ void frame_segment(const WfParams& w, const uint32_t*
                 }
             }
         }
-        // ---- a finished walk with nothing parked: the ray's result is final, its pixel's step is due ----
+        // ---- a finished walk with nothing parked: the ray's result is final (parked in `due` at the next hand-out) ----
         if ((fl & (kAlive | kOver | kPend)) == (kAlive | kOver)) fl = kDone;
+    }
+    if (COUNT) {  // engineering aid (RT_WALK_STATS), row 0: as the walks' rows
+        const unsigned long long r = wave_sum64(s_rays);
+        if (lane == 0u) {
+            unsigned long long* acc = w.rp.counters->walk[0];
+            const unsigned long long v0[8] = {r, s_trips, s_live, s_starved, s_stalled, 0ull, s_flush, s_refill};
+            for (int j = 0; j < 8; ++j) if (v0[j]) atomicAdd(&acc[j], v0[j]);
+        }
+    }
+}
+
+// The STEPPER of a workgroup: draws the runs of new pixels, and for each of its walkers in turn runs the steps that are due -
+// one pixel per lane, topped up with new pixels - and queues what goes on in that walker's `rdy`.
+template <bool FUSED, bool COUNT>
+__device__ __forceinline__ void frame_stepper(const WfParams& w, const uint32_t* __restrict__ queue, uint32_t n_queue, uint32_t wave, uint32_t n_waves,
+                                              uint32_t* __restrict__ run_ctr, FrameRings* __restrict__ rings, FrameCtl* __restrict__ ctl, uint32_t* __restrict__ mine_state, Ctx& cnt) {
+    const uint32_t lane = threadIdx.x & 63u;
+#ifndef RT_FRAME_STEPPER_PRIO
+#define RT_FRAME_STEPPER_PRIO 3
+#endif
+    // One stepper feeds three walkers: whenever it can issue, it should (the walkers of its SIMD are issue-hungry, and a stepper
+    // that gets a quarter of the issue slots starves all three: 28 of 64 lanes walking, 15.7 ms per cfg4 frame)
+    __builtin_amdgcn_s_setprio(RT_FRAME_STEPPER_PRIO);
+    RunCursor rc;
+    bool more = false;
+    if (rc.begin(n_queue, wave, n_waves, run_ctr, lane)) more = rc.dynamic;
+    else { rc.next = 0u; rc.seg_end = 0u; }
+    uint32_t& next = rc.next;
+    const uint32_t& seg_end = rc.seg_end;
+    // per walker, 8 words of this wave's own in LDS (`mine_state`, zeroed by the kernel; a rolled loop over the walkers - the step is
+    // ~1500 instructions, three copies of it would not fit the instruction cache): what this side has published (due_head,
+    // rdy_tail), its wrapped slots, the pixels the walker has in flight
+    uint32_t spins = 0;
+    unsigned long long s_batches = 0, s_step_lanes = 0, s_passes = 0, s_idle = 0;  // COUNT only
+
+    for (;;) {
+        bool stepped = false;
+#pragma nounroll
+        for (uint32_t v = 0; v < kFrameWalkers; ++v) {
+            uint32_t* st = mine_state + 8u * v;
+            uint32_t due_head_v = st[0], due_slot_v = st[1], rdy_tail_v = st[2], rdy_slot_v = st[3], in_flight_v = st[4];
+            if (next >= seg_end && more) more = rc.grab(n_queue, run_ctr, lane);  // on to another run, if any is left
+            FrameRings& R = rings[v];
+            FrameCtl& C = ctl[v];
+            const uint32_t due_n = ctl_load(&C.due_tail) - due_head_v;
+            const uint32_t rdy_n = rdy_tail_v - ctl_load(&C.rdy_head);
+            const uint32_t left = next < seg_end ? seg_end - next : 0u;
+            const uint32_t headroom = kPixelsInFlight - in_flight_v;
+            const uint32_t admissible = left < headroom ? left : headroom;
+            const uint32_t room = kRing - rdy_n;
+            const uint32_t want = room < 64u ? room : 64u;   // what goes on is queued in rdy: never more than it can take
+            const uint32_t avail = due_n + admissible;
+            const bool normal = avail >= 64u && want >= 48u;                       // a full wave of steps, and room for what they produce
+            const bool pressure = due_n + 16u >= kRing && want != 0u;               // due is about to fill up
+            const bool flush = avail != 0u && want != 0u && rdy_n == 0u && ctl_load(&C.starving) != 0u;  // the walker has nothing: whatever there is
+            if (COUNT && lane == 0u) ++s_passes;
+            if (!(normal || pressure || flush)) continue;
+            stepped = true;
+            const uint32_t d = due_n < want ? due_n : want;
+            const uint32_t a = (want - d) < admissible ? (want - d) : admissible;
+            const bool run = lane < d + a;
+            const bool primary = lane >= d;
+            if (COUNT && lane == 0u) { ++s_batches; s_step_lanes += d + a; }
+            // what goes on is put down in `rdy` behind its tail, lane by lane (d + a <= want <= its room), and closed up afterwards
+            uint32_t pslot = rdy_slot_v + lane;
+            pslot -= pslot >= kRing ? kRing : 0u;
+            uint32_t dslot = due_slot_v + lane;
+            dslot -= dslot >= kRing ? kRing : 0u;
+            bool goes_on = false;
+            if (run) {
+                uint32_t spix = 0u;
+                if (primary) {
+                    const uint32_t mine = next + (lane - d);
+                    const uint32_t entry = w.identity_queue ? mine : queue[mine];
+                    spix = w.identity_queue ? mine : (entry & kQueuePixel);
+                }
+                goes_on = frame_step<FUSED, false>(w, RingIO{R, dslot, pslot}, primary, spix, cnt);
+            }
+            const unsigned long long gm = __ballot(goes_on);
+            {   // close the gaps the pixels that ended have left (reads before writes: one wave, LDS in order)
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(gm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)gm, 0u));
+                const bool move = goes_on && rank != lane;
+                float4 m0, m1, m2, m3;
+                if (move) { m0 = R.rdy[0][pslot]; m1 = R.rdy[1][pslot]; m2 = R.rdy[2][pslot]; m3 = R.rdy[3][pslot]; }
+                if (move) {
+                    uint32_t to = rdy_slot_v + rank;
+                    to -= to >= kRing ? kRing : 0u;
+                    R.rdy[0][to] = m0; R.rdy[1][to] = m1; R.rdy[2][to] = m2; R.rdy[3][to] = m3;
+                }
+            }
+            const uint32_t n_on = (uint32_t)__popcll(gm);
+            if (n_on != 0u) {
+                rdy_tail_v += n_on;
+                rdy_slot_v += n_on;
+                rdy_slot_v -= rdy_slot_v >= kRing ? kRing : 0u;
+                ctl_store(&C.rdy_tail, rdy_tail_v);  // (release: the rays are in LDS before the count says so)
+            }
+            if (d != 0u) {
+                due_head_v += d;
+                due_slot_v += d;
+                due_slot_v -= due_slot_v >= kRing ? kRing : 0u;
+                ctl_store(&C.due_head, due_head_v);  // (release: the entries have been read before the slots are given back)
+            }
+            next += a;
+            in_flight_v = in_flight_v + a - (d + a - n_on);
+            st[0] = due_head_v; st[1] = due_slot_v; st[2] = rdy_tail_v; st[3] = rdy_slot_v; st[4] = in_flight_v;
+        }
+        if (stepped) { spins = 0u; continue; }
+        // nothing was due anywhere
+        bool all_idle = next >= seg_end && !more;
+        for (uint32_t v = 0; v < kFrameWalkers; ++v) all_idle = all_idle && mine_state[8u * v + 4u] == 0u;
+        if (all_idle) break;
+        if (COUNT && lane == 0u) ++s_idle;
+        if (++spins > kFrameSpinLimit) { if (lane == 0u) atomicAdd(&w.counts[RS_FRAME_STUCK], 1u); break; }
+        __builtin_amdgcn_s_sleep(4);
+    }
+#pragma unroll
+    for (uint32_t v = 0; v < kFrameWalkers; ++v) ctl_store(&ctl[v].quit, 1u);
+    if (COUNT && lane == 0u) {  // row 1: step batches, passes over a walker, step lanes, idle polls
+        unsigned long long* acc1 = w.rp.counters->walk[1];
+        const unsigned long long v1[8] = {s_batches, s_passes, s_step_lanes, s_idle, 0ull, 0ull, 0ull, 0ull};
+        for (int j = 0; j < 8; ++j) if (v1[j]) atomicAdd(&acc1[j], v1[j]);
     }
 }
 
@@ -2524,24 +2811,71 @@ template <bool FUSED, bool COUNT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_FRAME_WAVES, RT_FRAME_WAVES))) void wf_frame(const WfParams wk, uint32_t* __restrict__ run_ctr) {
     WfParams w = wk;
     if (!resolve_round(w)) return;
-    __shared__ float4 s_acc[2 * 256];
+    __shared__ FrameRings s_rings[kFrameWalkers];
+    __shared__ FrameCtl s_ctl[kFrameWalkers];
+    __shared__ uint32_t s_stepper[8 * kFrameWalkers];
     const uint32_t n_queue = w.n_prev_closest;
     if (n_queue == 0u) return;
-    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * 256u) >> 6;
+    if (threadIdx.x < kFrameWalkers * (uint32_t)(sizeof(FrameCtl) / 4u)) reinterpret_cast<uint32_t*>(s_ctl)[threadIdx.x] = 0u;
+    if (threadIdx.x < 8u * kFrameWalkers) s_stepper[threadIdx.x] = 0u;
+    __syncthreads();   // (the only barrier of the kernel: the counters start from zero)
+    const uint32_t role = threadIdx.x >> 6;
     Ctx cnt{w, 0, 0ull, 0ull, 0ull, false, false, 0u, 0u, make_float4(0.f, 0.f, 0.f, 0.f), false, {}, {}, {}, {}};
     unsigned long long tested = 0;
-    frame_segment<FUSED, COUNT>(w, w.q_prev_closest, n_queue, wave, n_waves, run_ctr, s_acc, cnt, tested);
+    if (role == 0u) frame_stepper<FUSED, COUNT>(w, w.q_prev_closest, n_queue, blockIdx.x, gridDim.x, run_ctr, s_rings, s_ctl, s_stepper, cnt);
+    else frame_walker<FUSED, COUNT>(w, s_rings[role - 1u], s_ctl[role - 1u], tested);
     if (COUNT) {
         add_ray_counters(w, cnt);
         if (tested) atomicAdd(&w.rp.counters->tests, tested);
     }
 }
 
-// the frames wf_frame is made for (everything else keeps the round machine)
+// ---- rounds of {closest-hit walk, step} (round 4) --------------------------------------------------------------------------
+// What wf_frame's measurements said: fusing walk and step into one launch costs the walk a third of its
+// waves (the step needs 128 registers, the walk 80, a kernel has one allocation) and that outweighs every barrier it removes.
+// What does carry over is the STEP itself: with the light loop's shadow rays tested on the spot - through the last light's tile,
+// the way wf_resume already treats a path's last hit - a pixel has ONE ray kind in flight, ever. The round machine shrinks to
+// {walk the closest-hit queue, step} per bounce: no shadow queue and no shadow walk (1.8 ms of launches per cfg4 frame, each
+// ray rebuilt from its hit point first), no second visit of a hit a round later (its point, normal, phase word stored and
+// read back, its material gathered twice), no stale-specular stragglers (the backward scan finishes inside the step), hence
+// no wf_finish. Per pixel and round the step reads the ray and its result (40 bytes) + the accumulators (32) and writes the
+// next ray + the accumulators (64): 136 bytes where wf_resume moves ~180 and the shadow walk another 48.
+// The step is frame_step with the pixel state in HBM (StateIO).
+// one step of every pixel of the round's closest-hit queue; what goes on is appended to the next round's
+#ifndef RT_STEP_BLOCKS
+#define RT_STEP_BLOCKS 0   // 1: the stale-specular scans' shadow rays through the block grid first (as wf_finish), 0: the fine grid only
+#endif
+template <bool FUSED, bool COUNT>
+__global__ __launch_bounds__(kResumeThreads) __attribute__((amdgpu_waves_per_eu(RT_RESUME_WAVES_PER_EU))) void wf_step(const WfParams wk) {
+    WfParams w = wk;
+    if (!resolve_round(w)) return;
+    if (blockIdx.x * kResumeThreads >= w.n_prev_closest) return;  // the grid is sized for the most the queue can hold
+    const uint32_t t = blockIdx.x * kResumeThreads + threadIdx.x;
+    Ctx cnt{w, 0, 0ull, 0ull, 0ull, false, false, 0u, 0u, make_float4(0.f, 0.f, 0.f, 0.f), false, {}, {}, {}, {}};
+    bool goes_on = false;
+    uint32_t pix = 0u;
+    if (t < w.n_prev_closest) {
+        const uint32_t entry = w.identity_queue ? t : w.q_prev_closest[t];
+        pix = entry & kQueuePixel;
+        goes_on = frame_step<FUSED, RT_STEP_BLOCKS != 0>(w, StateIO{w, pix}, w.first_round != 0u, pix, cnt);
+    }
+    block_push(goes_on, false, pix, w.q_closest, w.q_any, w.counts);
+    if (COUNT) add_ray_counters(w, cnt);
+}
+
+// the frames wf_frame / the {walk, step} rounds are made for (everything else keeps the round machine)
+static bool step_rounds_possible(const WfParams& w, int kernel);
 static bool frame_kernel_applies(const WfParams& w, int kernel) {
     const char* env = std::getenv("RT_FRAME_KERNEL");  // "1": on (read per launch: tests render both ways in one process)
     if (!(env && env[0] == '1')) return false;
+    return step_rounds_possible(w, kernel);
+}
+static bool step_rounds_apply(const WfParams& w, int kernel) {
+    const char* env = std::getenv("RT_STEP_ROUNDS");  // "1": on (read per launch)
+    if (!(env && env[0] == '1')) return false;
+    return step_rounds_possible(w, kernel);
+}
+static bool step_rounds_possible(const WfParams& w, int kernel) {
     if (std::getenv("RT_WALK2") || std::getenv("RT_WALK3")) return false;  // (a run that asks for one of the round machine's walks by name)
     return kernel == 2 && w.grid.enabled && !w.rp.scene.literal && !w.grid.has_triangles && w.grid.n_always == 0u && w.bgrid.enabled &&
            w.ltiles.enabled && w.ltiles.blocks_enabled && w.rp.scene.n_lights >= 1u && w.ltiles.light == w.rp.scene.n_lights - 1u;
@@ -2691,6 +3025,7 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
 
     static const bool one_stream = std::getenv("RT_WF_ONE_STREAM") != nullptr;  // measurement knob
     const bool use_frame = KERNEL == 2 && frame_kernel_applies(w, KERNEL);
+    const bool use_step = KERNEL == 2 && !use_frame && step_rounds_apply(w, KERNEL);  // rounds of {closest-hit walk, wf_step}: no shadow queue, no wf_finish
     auto enqueue_round = [&](bool first, uint64_t nc_max, uint64_t na_max) -> hipError_t {
         hipError_t e2;
         w.first_round = first ? 1u : 0u;
@@ -2758,12 +3093,16 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
             const dim3 grid = persistent_grid(nc_max, waves);
             if (w.count_rays) hipLaunchKernelGGL((wf_frame<FUSED, true>), grid, dim3(256), 0, stream, w, rs + kTicketBase + kTicketWords);
             else hipLaunchKernelGGL((wf_frame<FUSED, false>), grid, dim3(256), 0, stream, w, rs + kTicketBase + kTicketWords);
+        } else if (use_step) {
+            const dim3 grid((uint32_t)((nc_max + kResumeThreads - 1) / kResumeThreads));
+            if (w.count_rays) hipLaunchKernelGGL((wf_step<FUSED, true>), grid, dim3(kResumeThreads), 0, stream, w);
+            else hipLaunchKernelGGL((wf_step<FUSED, false>), grid, dim3(kResumeThreads), 0, stream, w);
         } else {
             hipLaunchKernelGGL((wf_resume<KERNEL, FUSED>), dim3((uint32_t)((total_max + kResumeThreads - 1) / kResumeThreads)),
                                dim3(kResumeThreads), 0, stream, w);
         }
         if ((e2 = hipGetLastError()) != hipSuccess) return e2;
-        hipLaunchKernelGGL(wf_advance, dim3(1), dim3(256), 0, stream, rs, (uint32_t)finish_threshold, use_grid ? 1u : 0u);
+        hipLaunchKernelGGL(wf_advance, dim3(1), dim3(256), 0, stream, rs, (uint32_t)finish_threshold, (use_grid && !use_step) ? 1u : 0u);
         return hipGetLastError();
     };
 
@@ -2773,17 +3112,18 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
     if (KERNEL == 1) batch = w.rp.scene.n_lights + 1u;
     else if (KERNEL == 2) batch = w.rp.scene.literal ? 8u : w.rp.max_bounces + 2u;
     if (batch > 12u) batch = 12u;
-    if (use_frame) batch = 1u;  // the first "round" is the whole frame; what it hands over goes to wf_finish (or, if many, to further rounds)
+    if (use_step) batch = std::min<uint32_t>(w.rp.max_bounces, 11u) + 1u;  // a step per ray of the deepest path: the primary ray and one per bounce
+    if (use_frame) batch = 1u;  // the first "round" is the whole frame (wf_frame leaves nothing behind: the queues it would fill stay empty)
     if (const char* env = std::getenv("RT_WF_BATCH")) batch = (uint32_t)std::max(1, std::atoi(env));
     bool first = true;
     uint64_t nc_max = n, na_max = 0;  // the first round traces the primary rays only
     for (;;) {
         for (uint32_t r = 0; r < batch; ++r) {
             if ((e = enqueue_round(first, nc_max, na_max)) != hipSuccess) return e;
-            if (first) { first = false; nc_max = (KERNEL == 0) ? 0 : n; na_max = (KERNEL == 0) ? 0 : n; }
+            if (first) { first = false; nc_max = (KERNEL == 0) ? 0 : n; na_max = (KERNEL == 0 || use_step) ? 0 : n; }
             if (nc_max + na_max == 0) break;
         }
-        if (use_grid) {
+        if (use_grid && !use_step) {
             // (wf_finish resumes pixels from their stored phase words and rays: never as a first round - with a batch of one
             //  round, RT_WF_BATCH=1, `w` would still carry the first round's flags here)
             w.first_round = 0u;
@@ -2796,12 +3136,13 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
         if (std::getenv("RT_ROUND_STATS"))  // engineering aid (with RT_WF_BATCH=1: after every round)
             std::fprintf(stderr, "[rounds] after %u round(s): closest queue %u, shadow queue %u, hand-over %u\n", buf.h_counts[RS_ROUNDS],
                          buf.h_counts[RS_N_CLOSEST], buf.h_counts[RS_N_ANY], buf.h_counts[RS_FINISH]);
+        if (buf.h_counts[RS_FRAME_STUCK] != 0u) return hipErrorLaunchFailure;  // wf_frame gave up on pixels (a logic error): no frame is better than a wrong one
         if (buf.h_counts[RS_FINISH] != 0u) break;  // 2: the queues ran empty; 1: wf_finish (enqueued above) took the rest
         if (nc_max + na_max == 0) break;
         // still going (long light scans, deep bounce chains): what is alive bounds every later queue
         const uint64_t alive = (uint64_t)buf.h_counts[RS_N_CLOSEST] + buf.h_counts[RS_N_ANY];
         nc_max = std::min<uint64_t>(n, alive);
-        na_max = std::min<uint64_t>(n, alive);
+        na_max = use_step ? 0 : std::min<uint64_t>(n, alive);
         batch = std::getenv("RT_ROUND_STATS") ? 1u : 8u;
     }
     if (rounds_out) *rounds_out = buf.h_counts[RS_ROUNDS];

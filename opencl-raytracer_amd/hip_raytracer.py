@@ -31,7 +31,7 @@ EXPORTS = [
     "rt_render_device", "rt_set_aux_device", "rt_render_aux", "rt_count_rays", "rt_get_stats",
     "rt_timing_reset", "rt_timing_summary", "rt_destroy", "rt_last_error", "rt_get_setup_times",
     "rt_create_multi", "rt_set_camera_multi", "rt_multi_frame_elems", "rt_render_multi", "rt_render_multi_device",
-    "rt_multi_context", "rt_multi_last_error", "rt_destroy_multi",
+    "rt_multi_context", "rt_multi_last_error", "rt_destroy_multi", "rt_count_rays_multi", "rt_get_stats_multi",
 ]
 
 
@@ -108,6 +108,10 @@ def load_library(path: os.PathLike | None = None) -> ctypes.CDLL:
     lib.rt_create_multi.argtypes = [ctypes.POINTER(vp), vp, u32, vp, u32, vp, u64, u32, i32, ctypes.POINTER(i32), u32, u64, u32]
     lib.rt_set_camera_multi.restype = i32
     lib.rt_set_camera_multi.argtypes = [vp, u32, u32, ctypes.c_float]
+    lib.rt_count_rays_multi.restype = i32
+    lib.rt_count_rays_multi.argtypes = [vp]
+    lib.rt_get_stats_multi.restype = i32
+    lib.rt_get_stats_multi.argtypes = [vp, ctypes.POINTER(RTStats)]
     lib.rt_multi_frame_elems.restype = u64
     lib.rt_multi_frame_elems.argtypes = [vp]
     lib.rt_render_multi.restype = i32
@@ -266,8 +270,8 @@ class HIPRaytracer:
 
 class MultiHIPRaytracer:
     """IRaytracer backend for several GPUs driven from ONE process through the C ABI (rt_create_multi): one context and one
-    host thread per device, interleaved row-tiles, tiles copied device-to-device to their place in the frame on
-    devices[0]. `devices` may repeat an ordinal (rehearsal on fewer GPUs). The torch.distributed flavour - one process
+    host thread per device, interleaved row-tiles; Render(): every device copies its tiles straight into the pinned host
+    frame (render_device: device-to-device to their place in a frame on devices[0]). `devices` may repeat an ordinal (rehearsal on fewer GPUs). The torch.distributed flavour - one process
     per GPU, RCCL exchange - is distributed.ShardedHIPRaytracer."""
 
     def __init__(self, objects, lights, rays, MAX_BOUNCES: int = 0, *, devices=(0,), kernel="shade_and_reflect",
@@ -322,8 +326,31 @@ class MultiHIPRaytracer:
         arr = np.ctypeslib.as_array(out, shape=(self.n_rays * self.elem_floats,)).copy()
         return arr.reshape(self.n_rays, 4) if self.elem_floats == 4 else arr
 
+    def count_rays(self) -> RTStats:
+        """Untimed counted render on every shard; the counters summed over the shards (the whole frame's)."""
+        self._check(self._lib.rt_count_rays_multi(self._m))
+        return self.stats()
+
+    def stats(self) -> RTStats:
+        st = RTStats()
+        self._check(self._lib.rt_get_stats_multi(self._m, ctypes.byref(st)))
+        return st
+
+    def render_host_ms(self, repeats: int = 3) -> float:
+        """Wall clock of the synchronous Render() (kernels + every device's copy into the pinned host frame), best of `repeats`."""
+        import time
+        best = None
+        out = ctypes.POINTER(ctypes.c_float)()
+        for _ in range(max(1, repeats)):
+            t0 = time.perf_counter()
+            self._check(self._lib.rt_render_multi(self._m, ctypes.byref(out)))
+            dt = (time.perf_counter() - t0) * 1e3
+            best = dt if best is None else min(best, dt)
+        return best
+
     def render_device(self, d_frame_ptr: int):
-        """The whole frame into device memory on devices[0] (frame_elems elements); returns when it is complete."""
+        """The whole frame into device memory on devices[0] (frame_elems elements); returns when it is complete. The buffer
+        must be idle on entry (hip_raytracer.h)."""
         self._check(self._lib.rt_render_multi_device(self._m, ctypes.c_void_p(d_frame_ptr)))
 
     def close(self):

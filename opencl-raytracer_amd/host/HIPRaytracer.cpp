@@ -88,7 +88,10 @@ cl_float4* HIPRaytracer::Render() {
 
 rt_stats_t HIPRaytracer::Stats() {
     rt_stats_t s;
-    rt_context* c = multi ? rt_multi_context(multi, 0) : ctx;  // (several GPUs: the first shard's)
-    if (rt_get_stats(c, &s) != RT_OK) throw std::runtime_error(std::string("HIPRaytracer::Stats: ") + rt_last_error(c));
+    if (multi) {  // several GPUs: the counters summed over the shards, the slowest shard's kernel time - the whole frame's figures
+        if (rt_get_stats_multi(multi, &s) != RT_OK) throw std::runtime_error(std::string("HIPRaytracer::Stats: ") + rt_multi_last_error(multi));
+        return s;
+    }
+    if (rt_get_stats(ctx, &s) != RT_OK) throw std::runtime_error(std::string("HIPRaytracer::Stats: ") + rt_last_error(ctx));
     return s;
 }

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in hip_raytracer.h but not exported"
     assert sorted(hr.EXPORTS) == declared_functions()
     lib.rt_abi_version.restype = ctypes.c_int
-    assert lib.rt_abi_version() == 2  # 2: NULL = legacy default stream, setup times, multi-device entry points
+    assert lib.rt_abi_version() == 3  # 3: multi-device stats, per-device host placement, ray-domain guard (history: hip_raytracer.h)
 
 
 def test_no_silent_cpu_fallback():

@@ -1,0 +1,91 @@
+"""GPU: round 4's two other routes through a large-scene shade_and_reflect frame - rounds of {closest-hit walk, wf_step}
+(RT_STEP_ROUNDS=1) and the whole frame in one persistent launch (wf_frame, RT_FRAME_KERNEL=1: stepper / walker waves, LDS
+rings) - against the round machine and the oracle. Both test every shadow ray inside the step (the last light's through its
+light tile, the stale-specular scans' through the grid) and call the round machine's own device functions: frames and ray
+counts must be identical, bit for bit, whatever the route (shade_and_reflect_kernel.cl:244-285)."""
+import numpy as np
+import pytest
+
+from helpers import R, camera, compare_frames, same_floats
+from test_block_walk_gpu import _scene
+
+pytestmark = pytest.mark.gpu
+
+ROUTES = {"rounds": {}, "step_rounds": {"RT_STEP_ROUNDS": "1"}, "frame_kernel": {"RT_FRAME_KERNEL": "1"}}
+
+
+def hip(*a, **k):
+    from opencl_raytracer_amd.hip_raytracer import HIPRaytracer
+    return HIPRaytracer(*a, **k)
+
+
+def _render_all(monkeypatch, make, want_stats=True):
+    out = {}
+    for name, env in ROUTES.items():
+        for k in ("RT_STEP_ROUNDS", "RT_FRAME_KERNEL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with make() as rt:
+            frame = rt.Render()
+            again = rt.Render()
+            st = rt.count_rays() if want_stats else None
+            t, idx = rt.render_aux()
+        assert np.array_equal(frame.view(np.uint32), again.view(np.uint32)), name
+        out[name] = (frame, (st.rays_reference, st.rays_traced, st.hit_pixels) if st else None, t, idx, st.rounds if st else 0)
+    return out
+
+
+@pytest.mark.parametrize("depth", [0, 1, 4])
+def test_three_routes_one_frame(monkeypatch, depth):
+    rng = np.random.default_rng(21 + depth)
+    objs, lights = _scene(rng, 1600, 4, 40, lights=3)
+    W, H = 192, 136
+    z = float(camera.camera_z(H))
+    got = _render_all(monkeypatch, lambda: hip(objs, lights, None, depth, camera=(W, H, z)))
+    base = got["rounds"]
+    assert (base[3] >= 0).sum() > 2000
+    for name in ("step_rounds", "frame_kernel"):
+        assert np.array_equal(got[name][0].view(np.uint32), base[0].view(np.uint32)), name
+        assert got[name][1] == base[1], name
+        assert np.array_equal(got[name][3], base[3]) and same_floats(got[name][2], base[2]), name
+    assert got["step_rounds"][4] <= depth + 1 and got["frame_kernel"][4] <= 1   # no shadow rounds, no stragglers
+
+
+def test_routes_against_the_oracle_with_stale_specular_scans(monkeypatch, restatement):
+    """Many hits face away from the last light but not from earlier ones (lights on opposite sides of the cloud): the light
+    loop's backward scan goes on to earlier lights - inside the step on the new routes, as queued shadow rays on the old one."""
+    rng = np.random.default_rng(5)
+    objs, _ = _scene(rng, 700, 2, 20, lights=1)
+    props = R.LightProperties((.1, .1, .1), (.5, .5, .5), (.6, .6, .6))
+    lights = R.lights_array([R.make_light(props, position=(-60.0, 10.0, -50.0, 1.0)), R.make_light(props, position=(0.0, 70.0, -55.0, 1.0)),
+                             R.make_light(props, position=(0.3, -0.2, -1.0, 0.0)), R.make_light(props, position=(55.0, -5.0, 12.0, 1.0))])
+    rays = camera.crop_rays(1024, 1024, 512 - 48, 512 - 32, 96, 64)
+    want = restatement[True].render("shade_and_reflect", objs, lights, rays, 3)
+    got = _render_all(monkeypatch, lambda: hip(objs, lights, rays, 3))
+    for name, (frame, counts, t, idx, _) in got.items():
+        assert compare_frames(frame, want["out"]) <= 1e-5, name
+        assert counts[0] == want["rays_ref"], name
+        assert np.array_equal(idx, want["hit_index"]) and same_floats(t, want["hit_t"]), name
+    for name in ("step_rounds", "frame_kernel"):
+        assert np.array_equal(got[name][0].view(np.uint32), got["rounds"][0].view(np.uint32)), name
+        assert got[name][1] == got["rounds"][1], name
+
+
+def test_routes_on_a_shard_with_a_ragged_last_tile(monkeypatch):
+    """Interleaved row-tiles with padding work-items (wf_begin builds the first queue): rank 1 of 3."""
+    from opencl_raytracer_amd import sharding, synthetic
+    objs, lights = synthetic.spheres_and_lights(1200, 5)
+    W, H = 160, 104  # 104 rows in tiles of 16: 6.5 tiles
+    z = float(camera.camera_z(H))
+    frames = {}
+    for name, env in ROUTES.items():
+        for k in ("RT_STEP_ROUNDS", "RT_FRAME_KERNEL"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with hip(objs, lights, None, 3, camera=(W, H, z)) as rt:
+            rt.set_shard(sharding.tile_rays_for_rows(W, 16), 1, 3)
+            frames[name] = rt.Render()
+    for name in ("step_rounds", "frame_kernel"):
+        assert np.array_equal(frames[name].view(np.uint32), frames["rounds"].view(np.uint32)), name

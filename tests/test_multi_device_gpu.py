@@ -47,6 +47,25 @@ def test_grid_path_camera_mode_and_device_frame():
     assert np.array_equal(dev.view(np.uint32), want.view(np.uint32))
 
 
+def test_stats_cover_the_whole_frame_and_render_twice_reuses_the_workers():
+    """Stats() of the several-GPU raytracer used to be shard 0's alone. rt_get_stats_multi sums the counters over the
+    shards; the host threads live as long as the raytracer (many frames through the same workers)."""
+    objs, lights = random_scene(260, 40, 4, seed=43, spread=14.0, zrange=(-60.0, -12.0))
+    W, H = 160, 120
+    z = float(camera.camera_z(H))
+    with HIPRaytracer(objs, lights, None, 3, camera=(W, H, z)) as rt:
+        want = rt.Render()
+        one = rt.count_rays()
+    with MultiHIPRaytracer(objs, lights, None, 3, devices=[0, 0, 0, 0], camera=(W, H, z)) as rt:
+        st = rt.count_rays()
+        assert (st.rays_traced, st.rays_reference, st.hit_pixels) == (one.rays_traced, one.rays_reference, one.hit_pixels)
+        assert st.local_rays == rt.frame_elems >= W * H
+        for _ in range(6):
+            got = rt.Render()
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        assert rt.render_host_ms(2) > 0.0
+
+
 def test_hittest_kernel_and_uneven_shares():
     objs, lights = random_scene(5, 3, 1, seed=47)
     W, H = 64, 40  # 40 rows / 8-row tiles = 5 tiles over 4 shards: shares of 2, 1, 1, 1
