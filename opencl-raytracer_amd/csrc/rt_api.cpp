@@ -807,6 +807,10 @@ int build_walk_blocks(rt_context* c, uint32_t n, const std::vector<Bound>& sph, 
     for (int a = 0; a < 3; ++a) c0[a] = (float)((double)lof[a] + (0.5 - B) * (double)cellf);
     const volatile float inv_step_v = 128.0f / cellf;
     const float inv_step = inv_step_v;
+    // D: no ray of a frame starts outside the grid box - build_grid's box holds every uploaded primary origin (origin_lo / hi;
+    // the pinhole camera's (0,0,0) is their initial value) and secondary rays start on object surfaces - so |oc| never exceeds
+    // the box's diagonal (+ the two border cells the walks may look at). The walks' `t_enter <= 4096 dmin` admission is therefore
+    // always met (t_enter = 0); what their `tame` test really screens is |d|^2 (the bound and the admission rule agree)
     double Dmax = 0;
     for (int a = 0; a < 3; ++a) Dmax += (ghi[a] - glo[a] + 2 * cell) * (ghi[a] - glo[a] + 2 * cell);
     Dmax = std::sqrt(Dmax);

@@ -1203,7 +1203,10 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
                 bool start = false, brute = false;
                 const Walk w0 = walk_begin(bg, ray, 3.0e38f);  // (a ray with a NaN in it: not alive)
                 if (w0.alive) {
-                    // (walk_segment: the rays this walk is made for; anything else tests every object here and now)
+                    // (walk_segment: the rays this walk is made for; anything else tests every object here and now. Since round 4 a
+                    // frame whose PRIMARY directions fail this window is rendered by the literal loops as a whole - rt_create's ray scan,
+                    // rt_set_camera - and every origin lies in the grid box, so what is left for this branch are secondary rays with
+                    // |d|^2 outside (1e-30, 1e30): a light within 1e-15 of a hit point. Rare, slow, and the same result.)
                     const float dmin = __builtin_fminf(__builtin_fminf(w0.dtx, w0.dty), w0.dtz);
                     const bool tame = dd > 1.0e-30f && dd < 1.0e30f && w0.t_enter <= 4096.f * dmin;
                     brute = !tame;
