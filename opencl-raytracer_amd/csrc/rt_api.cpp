@@ -75,6 +75,11 @@ struct rt_context {
     size_t d_out_bytes = 0;
     void* h_out = nullptr;  // context-owned pinned host framebuffer (Render()'s return value)
     size_t h_out_bytes = 0;
+    // rt_render in two passes (render_in_passes): the second pass's device buffer, the stream the read-backs run on, an event per pass
+    void* d_out2 = nullptr;
+    size_t d_out2_bytes = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_pass[2] = {nullptr, nullptr};
 
     float* aux_t = nullptr;  // caller-owned device buffers for the next render
     int32_t* aux_index = nullptr;
@@ -1806,9 +1811,80 @@ int rt_render_device(rt_context* c, void* d_out, void* hip_stream) {
     return do_launch(c, d_out, static_cast<hipStream_t>(hip_stream), false);
 }
 
+// The synchronous Render() of a LARGE frame, in two passes: the frame is cut into interleaved row-tiles exactly as for two GPUs
+// (rt_set_shard's partition), pass 0 renders the even tiles, pass 1 the odd ones, and pass 0's tiles travel to the pinned host
+// frame - one strided device-to-host copy on a stream of its own - WHILE pass 1 renders. The blocking read-back of 268 MB
+// (OpenCLRaytracer.cpp:94) is 4.9 ms behind an 11.8 ms cfg4 render; half of it now hides. MEASURED before it was built, with two
+// whole contexts on one GPU (tools/ab/multi_wall.py): 16.87 -> 15.45 ms; four contexts: 18.07 (every pass pays its own drains).
+// Only for frames of the large-scene path with >= 4 M rays that the caller has not sharded himself; RT_RENDER_PASSES=1 switches
+// it off. The pixels are the one-pass frame's, bit for bit (a shard is the same arithmetic on a subset of the rays).
+static int render_in_passes(rt_context* c, const float** out) {
+    constexpr uint32_t K = 2;
+    const uint64_t n_rays = c->n_rays;
+    const uint64_t tile_rays = (c->pinhole && c->width) ? 16ull * c->width : 65536ull;
+    const uint64_t tiles = (n_rays + tile_rays - 1) / tile_rays;
+    const size_t elem = elem_bytes(c), tile_bytes = (size_t)tile_rays * elem;
+    const size_t host_bytes = (size_t)tiles * tile_bytes;  // whole tiles: the ragged last one is padded behind the frame's end
+    if (host_bytes > c->h_out_bytes) {
+        if (c->h_out) (void)hipHostFree(c->h_out);
+        c->h_out = nullptr;
+        c->h_out_bytes = 0;
+        RT_HIP(c, hipHostMalloc(&c->h_out, host_bytes, hipHostMallocDefault));
+        c->h_out_bytes = host_bytes;
+    }
+    if (!c->copy_stream) RT_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (uint32_t k = 0; k < K; ++k)
+        if (!c->ev_pass[k]) RT_HIP(c, hipEventCreateWithFlags(&c->ev_pass[k], hipEventDisableTiming));
+    int rc = RT_OK;
+    for (uint32_t k = 0; k < K && rc == RT_OK; ++k) {
+        c->tile_rays = tile_rays;
+        c->rank = k;
+        c->world = K;
+        c->n_local = local_count(n_rays, tile_rays, k, K);
+        const size_t need = (size_t)c->n_local * elem;
+        void** buf = k ? &c->d_out2 : &c->d_out;
+        size_t* have = k ? &c->d_out2_bytes : &c->d_out_bytes;
+        if (need > *have) {
+            if (*buf) (void)hipFree(*buf);
+            *buf = nullptr;
+            *have = 0;
+            const hipError_t e = hipMalloc(buf, need ? need : 16);
+            if (e != hipSuccess) { rc = fail_hip(c, e, "hipMalloc (pass buffer)"); break; }
+            *have = need;
+        }
+        rc = do_launch(c, *buf, c->stream, false);
+        if (rc != RT_OK) break;
+        const uint64_t mine = tiles / K + ((tiles % K) > k ? 1 : 0);
+        hipError_t e = hipEventRecord(c->ev_pass[k], c->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, c->ev_pass[k], 0);
+        if (e == hipSuccess && mine)  // tile j of this pass is tile j * K + k of the frame
+            e = hipMemcpy2DAsync(static_cast<char*>(c->h_out) + (size_t)k * tile_bytes, (size_t)K * tile_bytes, *buf, tile_bytes, tile_bytes, (size_t)mine,
+                                 hipMemcpyDeviceToHost, c->copy_stream);
+        if (e != hipSuccess) rc = fail_hip(c, e, "read-back of a pass");
+    }
+    c->tile_rays = 0;
+    c->rank = 0;
+    c->world = 1;
+    c->n_local = n_rays;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    const hipError_t e2 = hipStreamSynchronize(c->copy_stream);  // Render() is synchronous (OpenCLRaytracer.cpp:94)
+    if (rc != RT_OK) return rc;
+    if (e == hipSuccess) e = e2;
+    if (e != hipSuccess) return fail_hip(c, e, "hipStreamSynchronize");
+    *out = static_cast<const float*>(c->h_out);
+    return RT_OK;
+}
+
 int rt_render(rt_context* c, const float** out) {
     if (!c || !out) return RT_ERR_INVALID_ARGUMENT;
     RT_DEVICE(c);
+    {
+        const char* env = std::getenv("RT_RENDER_PASSES");  // "1": one pass whatever the frame; "2": two passes whatever its size (tests)
+        const bool off = env && env[0] == '1', forced = env && env[0] == '2';
+        if (!off && c->world <= 1 && (forced || c->n_rays >= (1ull << 22)) && c->n_rays > 0 && c->n_local == c->n_rays && use_wavefront(c) &&
+            (c->pinhole || c->have_rays))
+            return render_in_passes(c, out);
+    }
     int rc = ensure_out(c);
     if (rc) return rc;
     rc = ensure_host_out(c);
@@ -1945,7 +2021,10 @@ void rt_destroy(rt_context* c) {
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_out2) (void)hipFree(c->d_out2);
     if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    for (hipEvent_t ev : c->ev_pass) if (ev) (void)hipEventDestroy(ev);
     if (c->d_counters) (void)hipFree(c->d_counters);
     free_wavefront(c);
     for (uint32_t i = 0; i < c->ev_begin_made; ++i) (void)hipEventDestroy(c->ev_begin[i]);

@@ -89,3 +89,26 @@ def test_routes_on_a_shard_with_a_ragged_last_tile(monkeypatch):
             frames[name] = rt.Render()
     for name in ("step_rounds", "frame_kernel"):
         assert np.array_equal(frames[name].view(np.uint32), frames["rounds"].view(np.uint32)), name
+
+
+@pytest.mark.parametrize("mode", ["camera", "ray_buffer"])
+def test_render_in_two_passes_is_the_one_pass_frame(monkeypatch, mode):
+    """rt_render of a large frame renders the even and the odd row-tiles one after the other and copies the first half to the
+    host while the second renders (rt_api.cpp: render_in_passes; frames of >= 4 M rays, forced here with RT_RENDER_PASSES=2):
+    same pixels as the one-pass Render(), ragged last tile included, call after call."""
+    from opencl_raytracer_amd import synthetic
+    objs, lights = synthetic.spheres_and_lights(900, 4)
+    W, H = 168, 104   # 6.5 tiles of 16 rows
+    z = float(camera.camera_z(H))
+    make = (lambda: hip(objs, lights, None, 3, camera=(W, H, z))) if mode == "camera" else (lambda: hip(objs, lights, camera.primary_rays(W, H), 3, raygen=False))
+    monkeypatch.setenv("RT_RENDER_PASSES", "1")
+    with make() as rt:
+        want = rt.Render()
+        assert rt.stats().wavefront == 1
+    monkeypatch.setenv("RT_RENDER_PASSES", "2")
+    with make() as rt:
+        for _ in range(3):
+            got = rt.Render()
+            assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        t, idx = rt.render_aux()            # (the context is back to the whole frame afterwards)
+        assert len(idx) == W * H and rt.stats().local_rays == W * H
