@@ -24,7 +24,9 @@ RT_WALK_STATS=1 python3 bench.py --no-cpu-baseline --no-extra --steps 1 --warmup
 for w in cfg2 cfg3 cfg5base cfg5; do python3 bench.py --workload $w --no-cpu-baseline > $F/bench_$w.json 2> $F/bench_$w.err; echo "$w done"; done
 python3 bench.py --workload cfg4 --ray-buffer --no-cpu-baseline --no-extra > $F/bench_cfg4_raybuffer.json 2> /dev/null || true
 for n in 2 4; do RT_BENCH_ONE_GPU=1 python3 bench.py --gpus $n --no-cpu-baseline --no-extra > $F/bench_gloo_one_gpu_n$n.json 2> $F/bench_gloo_n$n.err || true; done   # (bench.py starts its own ranks)
-# kernel timelines of one frame: the whole cfg4 frame, the same with the two walks of a round one after the other, rank 0's share at world 8, cfg5
+# kernel timelines of one frame (RT_RENDER_PASSES=1: the last frame of a run is one of bench.py's Render() calls - keep it whole):
+export RT_RENDER_PASSES=1
+# ... the whole cfg4 frame, the same with the two walks of a round one after the other, rank 0's share at world 8, cfg5
 (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace -d $F/tr_a -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline > /dev/null 2>&1) || true
 python3 tools/ab/timeline.py $(find $F/tr_a -name "*kernel_trace.csv" | head -1) > $F/timeline_cfg4.txt 2>&1 || true
 (cd /tmp && export TMPDIR=/tmp && RT_WF_ONE_STREAM=1 rocprofv3 --kernel-trace -d $F/tr_b -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline > /dev/null 2>&1) || true

@@ -14,6 +14,7 @@ RT_STEP_ROUNDS=1 python3 bench.py --no-cpu-baseline --no-extra --steps 5 --warmu
 RT_FRAME_KERNEL=1 python3 tools/ab/share_time.py 16 > $F/share_rehearsal_frame_kernel.json 2> /dev/null || true
 RT_STEP_ROUNDS=1 python3 tools/ab/share_time.py 16 > $F/share_rehearsal_step_rounds.json 2> /dev/null || true
 RT_FRAME_KERNEL=1 RT_WALK_STATS=1 python3 bench.py --no-cpu-baseline --no-extra --steps 1 --warmup 0 2> $F/ws_raw.txt > /dev/null; grep -E "walk|blocks" $F/ws_raw.txt > $F/walk_stats_frame_kernel.txt; rm -f $F/ws_raw.txt
+export RT_RENDER_PASSES=1   # (timelines: the last frame of a run is one of bench.py's Render() calls - keep it whole)
 (cd /tmp && export TMPDIR=/tmp && RT_STEP_ROUNDS=1 rocprofv3 --kernel-trace -d $F/tr_e -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline > /dev/null 2>&1) || true
 python3 tools/ab/timeline.py $(find $F/tr_e -name "*kernel_trace.csv" | head -1) > $F/timeline_cfg4_step_rounds.txt 2>&1 || true
 (cd /tmp && export TMPDIR=/tmp && RT_FRAME_KERNEL=1 rocprofv3 --kernel-trace -d $F/tr_f -o p --output-format csv -- python3 $R/bench.py --steps 2 --warmup 1 --no-extra --no-cpu-baseline > /dev/null 2>&1) || true

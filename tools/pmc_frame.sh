@@ -18,6 +18,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/frame_$KEY
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# the frame the counters are read from is the LAST one of the run - one of bench.py's synchronous Render() calls
+# (render_wall_ms_incl_d2h); since round 4 rt_render cuts a large frame into two passes, so keep it to one here: a whole frame
+export RT_RENDER_PASSES=1
 BENCH="python3 $R/bench.py --workload $W --steps 2 --warmup 1 --no-extra --no-cpu-baseline $FLAGS"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o p --output-format csv -- $BENCH > $OUT/trace.json 2> $OUT/trace.err
 echo "pass 1 (kernel trace) done"
