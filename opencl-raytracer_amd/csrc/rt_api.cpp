@@ -1882,7 +1882,7 @@ int rt_render(rt_context* c, const float** out) {
         const char* env = std::getenv("RT_RENDER_PASSES");  // "1": one pass whatever the frame; "2": two passes whatever its size (tests)
         const bool off = env && env[0] == '1', forced = env && env[0] == '2';
         if (!off && c->world <= 1 && (forced || c->n_rays >= (1ull << 22)) && c->n_rays > 0 && c->n_local == c->n_rays && use_wavefront(c) &&
-            (c->pinhole || c->have_rays))
+            (c->pinhole || c->have_rays) && !c->aux_t && !c->aux_index)  // (aux buffers are indexed by work-item of ONE whole-frame launch)
             return render_in_passes(c, out);
     }
     int rc = ensure_out(c);

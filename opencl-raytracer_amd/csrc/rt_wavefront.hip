@@ -1163,7 +1163,7 @@ __device__ __forceinline__ void block_segment(const WfParams& w, const uint32_t*
     const float wnx_f = (float)bg.wnx, wny_f = (float)bg.wny;
 
     unsigned long long s_rays = 0, s_trips = 0, s_live = 0, s_fetch = 0, s_pre = 0, s_flush = 0, s_refill = 0;  // STATS only
-    unsigned long long t_dry = 0, s_sum_after = 0; uint32_t my_trips = 0, max_trips = 0, trips_after = 0;  // STATS + RT_STATS_TAIL
+    unsigned long long t_dry = 0; uint32_t my_trips = 0, max_trips = 0, trips_after = 0;  // STATS + RT_STATS_TAIL
     // The lane's state bits live in ONE vector register and are changed with vector and / or: as `bool`s carried round
     // the loop the compiler keeps them as 64-bit lane masks in scalar registers, and every merge of divergent paths costs
     // an andn2 / and / or triple per flag (round 2's walk: 0.75 scalar instructions per vector instruction).
