@@ -172,7 +172,8 @@ int rt_timing_summary(rt_context* ctx, double* sum_ms, uint32_t* launches);
  * OpenCLRaytracer.cpp:13-74): milliseconds of wall clock spent in rt_create and, for the per-camera screen tiles and the
  * large-scene path's state buffers, in the first render. */
 typedef struct rt_setup_times_t {
-    double create_ms;        /* rt_create as a whole                                                          */
+    double create_ms;        /* rt_create as a whole (incl. the HIP runtime's start-up when rt_create is the process's
+                                first HIP call: ~140 ms that belong to no phase below)                          */
     double upload_ms;        /* record re-pack + uploads (objects, lights, rays)                               */
     double grid_ms;          /* conservative grid + the record table of the unified walk (0 for small scenes)  */
     double blocks_ms;        /* the closest-hit walk's coarse grid of 32-byte blocks                           */

@@ -1610,9 +1610,16 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         if (e2_ != hipSuccess) { rc = fail_hip(c, e2_, #call); return bail(rc); } \
     } while (0)
 
+    const bool trace = std::getenv("RT_SETUP_TRACE") != nullptr;  // engineering aid: where rt_create's time goes
+    StopWatch swt;
+    auto lap = [&](const char* what) { if (trace) std::fprintf(stderr, "[rt_create] %-28s %8.2f ms\n", what, swt.lap_ms()); };
     DeviceGuard guard(device);  // restores the caller's current device on every return below
     if (!guard.ok) { rc = fail_hip(c, guard.err, "hipSetDevice"); return bail(rc); }
     RT_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    lap("device + stream");
+    // (when rt_create is the process's first HIP call this is where the runtime starts up and the device context is made: ~140 ms
+    //  on the test boxes, MEASURED - it stays in create_ms, which is what the caller waits for, but is no part of the upload)
+    (void)sw.lap_ms();
     for (uint32_t i = 0; i < kTimingSlots; ++i) {
         RT_TRY(hipEventCreate(&c->ev_begin[i]));
         c->ev_begin_made = i + 1;
@@ -1620,6 +1627,7 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         c->ev_end_made = i + 1;
     }
     RT_TRY(hipMalloc((void**)&c->d_counters, sizeof(rt::Counters)));
+    lap("events + counters");
 
     {
         std::vector<rt::HotPair> pairs;
@@ -1627,6 +1635,7 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         std::vector<rt::ColdObject> cold;
         repack_objects(static_cast<const rt_object_data*>(objs), n_objs, pairs, hot, cold);
         c->n_pairs = (uint32_t)pairs.size();
+        lap("repack_objects");
         RT_TRY(hipMalloc((void**)&c->d_pairs, sizeof(rt::HotPair) * (pairs.size() + 1)));
         RT_TRY(hipMalloc((void**)&c->d_shadow_pairs, sizeof(rt::HotPair) * (pairs.size() + 1)));
         if (!pairs.empty()) {
@@ -1645,6 +1654,7 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
             repack_objects(sorted.data(), n_objs, spairs, shot, scold);
             RT_TRY(hipMemcpy(c->d_shadow_pairs, spairs.data(), sizeof(rt::HotPair) * spairs.size(), hipMemcpyHostToDevice));
         }
+        lap("pair streams (sort, upload)");
         // one spare record keeps the arrays non-null for n_objs == 0
         RT_TRY(hipMalloc((void**)&c->d_hot, sizeof(rt::HotObject) * (size_t)(n_objs + 1)));
         RT_TRY(hipMalloc((void**)&c->d_cold, sizeof(rt::ColdObject) * (size_t)(n_objs + 1)));
@@ -1679,6 +1689,7 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
             RT_TRY(hipMemcpy(c->d_objrec, rec.data(), sizeof(rt::ObjectRecord) * rec.size(), hipMemcpyHostToDevice));
         }
     }
+    lap("hot / cold / object records");
     RT_TRY(hipMalloc((void**)&c->d_lights, sizeof(rt::LightRec) * (size_t)(n_lights + 1)));
     if (n_lights) RT_TRY(hipMemcpy(c->d_lights, lights, sizeof(rt::LightRec) * n_lights, hipMemcpyHostToDevice));
 
@@ -1702,6 +1713,7 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         const rt_object_data& o = static_cast<const rt_object_data*>(objs)[i];
         if (o.type <= 1u && !std::isfinite(object_bound(o).r)) { c->flags |= RT_FLAG_LITERAL; c->forced_literal = true; }
     }
+    lap("instance checks");
     c->base_flags = c->flags;
     if (rays && n_rays) {
         const rt_ray* r = static_cast<const rt_ray*>(rays);
@@ -1733,7 +1745,9 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
     }
 #undef RT_TRY
     apply_ray_domain(c);
+    lap("ray scan + upload");
     (void)hipDeviceSynchronize();
+    lap("device synchronise");
     c->setup.upload_ms = sw.lap_ms();
     if (n_objs >= kWavefrontGridMinObjects || (flags & RT_FLAG_WAVEFRONT) || c->has_triangles) {
         rc = build_grid(c, static_cast<const rt_object_data*>(objs), n_objs);
