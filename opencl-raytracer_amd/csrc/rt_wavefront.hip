@@ -195,8 +195,10 @@ __device__ __forceinline__ void push(uint32_t* queue, uint32_t* counter, uint64_
 // atomics per microsecond on this chip, so one per wave (262 144 waves per round at 4096^2) would cost 3 ms a
 // round. Order inside the workgroup is preserved (neighbouring pixels stay neighbours in the next trace).
 #ifndef RT_RESUME_THREADS
-#define RT_RESUME_THREADS 1024
-#endif
+#define RT_RESUME_THREADS 512   // threads per workgroup of wf_begin / wf_resume / wf_step. MEASURED (round 4, cfg4 frame, two runs): 1024 (round 2's
+#endif                          // choice, when one atomic per workgroup mattered most): 11.87 / 11.77 ms, 512: 11.65 / 11.56, 256: 12.05 / 11.96 - a
+                                // 1 024-thread workgroup is ALL sixteen wave slots of a CU at 4 waves per SIMD: the CU idles until its slowest wave is done
+
 constexpr int kResumeThreads = RT_RESUME_THREADS;
 constexpr uint32_t kQueueAlsoShadow = 0x80000000u;  // flag on a closest-queue entry (pixel ids are < 2^31: launch_wavefront checks)
 constexpr uint32_t kQueuePixel = 0x7fffffffu;
