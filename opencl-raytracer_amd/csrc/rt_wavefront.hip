@@ -2927,8 +2927,10 @@ static inline dim3 grid_for(uint64_t n) { return dim3((uint32_t)((n + 255u) / 25
 // size, in effect one after the other) 19.6 ms; 6144 / 2048 20.15; 5120 / 2048 20.2; 5120 / 1024 20.8; 4096 / 2048 21.7 -
 // the closest-hit walk needs every slot it can get, the knobs stay at "full size".
 #ifndef RT_MAX_WAVES_CLOSEST_SHARED
-#define RT_MAX_WAVES_CLOSEST_SHARED RT_MAX_WAVES
-#endif
+#define RT_MAX_WAVES_CLOSEST_SHARED 5120   // round 4 (block walk + light-tile blocks): the closest-hit walk of a big round at FIVE waves per SIMD, the sixth
+#endif                                     // slot left to the shadow walk - MEASURED, closest / shadow caps, cfg4 frame, two runs each: 8192 / 4096 (round 3's)
+                                           // 11.68 / 11.70 ms; 5120 / 2560: 11.38 / 11.48; 5120 / 3072: 11.44 / 11.50; 5120 / 4096: 11.50 / 11.57;
+                                           // 4864 / 3072: 11.53 / 11.58; 5376 / 3072: 11.54 / 11.55; 4096 / 4096: 12.08 (tools/ab/env_sweep_caps.py)
 #ifndef RT_MAX_WAVES_ANY_SHARED
 #define RT_MAX_WAVES_ANY_SHARED RT_MAX_WAVES
 #endif
@@ -2950,13 +2952,14 @@ static void launch_persistent(const WfParams& w, uint64_t n_max, uint32_t* ticke
     // The shadow walk (light tiles: two or three short trips per ray) is bound by what a wave costs to start, not by how many
     // rays are in flight: MEASURED, rank 0's share of the cfg4 frame at world = 1 / 2 / 4 / 8 with its wave cap at 8192:
     // 17.44 / 9.51 / 5.57 / 3.59 ms; 4096: 17.40 / 9.34 / 5.31 / 3.39; 2048: 18.15 / 9.57 / 5.36 / 3.32; 1024: 20.2 / 10.6 / 5.9 / 3.56.
-    uint64_t any_cap = std::min<uint64_t>(RT_MAX_WAVES_ANY_SHARED, n_max <= (3ull << 20) ? 2048u : 4096u);
+    const bool mesh = w.grid.has_triangles != 0u;  // (meshes keep round 3's caps - their shadow walk is the heavier kernel: cfg5 38.4 / 38.9 ms against 40.0 / 39.4 with the new ones)
+    uint64_t any_cap = std::min<uint64_t>(RT_MAX_WAVES_ANY_SHARED, n_max <= (3ull << 20) ? 2048u : (mesh ? 4096u : 2560u));  // (round 4: 2560 beside a closest-hit walk of 5120, see above)
     // Round 3, block walk: a SMALL closest-hit queue (one rank's share of the frame at 8 ranks: 2.1 M pixels) is better served by
     // 4 waves per SIMD than by all 6 - the queue holds only ~3 rays per lane slot, the launch is mostly its own tail, and the
     // shadow walk finds free slots beside it instead of running in that tail. MEASURED, rank 0's share at world = 1 / 2 / 4 / 8,
     // closest / shadow wave caps: 8192 / 4096|2048: 12.66 / 6.84 / 3.94 / 2.55 ms; 4096 / 2048 everywhere: 12.97 / 6.98 / 3.98 / 2.32;
     // 5120 / 1024: 13.49 / 7.10 / 3.96 / 2.39.
-    uint64_t closest_cap = shared ? (n_max <= (3ull << 20) ? std::min<uint64_t>(RT_MAX_WAVES_CLOSEST_SHARED, 4096u) : RT_MAX_WAVES_CLOSEST_SHARED) : RT_MAX_WAVES;
+    uint64_t closest_cap = shared ? (n_max <= (3ull << 20) ? std::min<uint64_t>(RT_MAX_WAVES_CLOSEST_SHARED, 4096u) : (mesh ? RT_MAX_WAVES : RT_MAX_WAVES_CLOSEST_SHARED)) : RT_MAX_WAVES;
     if (const char* env = std::getenv("RT_WAVES_CLOSEST")) closest_cap = (uint64_t)std::max(64, std::atoi(env));  // measurement knobs
     if (const char* env = std::getenv("RT_WAVES_ANY")) any_cap = (uint64_t)std::max(64, std::atoi(env));
     const dim3 grid = persistent_grid(n_max, ANY ? any_cap : closest_cap), block(256);
