@@ -139,8 +139,9 @@ uint64_t rt_local_rays(const rt_context* ctx);
  *   kernel 0   : rt_local_rays() x float; misses are 3.402823466e+38f
  * The buffer is overwritten by the next call and freed by rt_destroy.
  * A large frame of the large-scene path (>= 4 M rays, not sharded by the caller) is rendered in two passes over interleaved
- * row-tiles, the first pass's read-back running while the second renders: same pixels, the blocking copy
- * (OpenCLRaytracer.cpp:94) half hidden. RT_RENDER_PASSES=1 in the environment keeps it to one pass. */
+ * 16-row tiles - three tiles of every four, then the fourth - the first pass's read-back running while the second renders: same
+ * pixels, three quarters of the blocking copy (OpenCLRaytracer.cpp:94) hidden. RT_RENDER_PASSES=1 in the environment keeps it
+ * to one pass, RT_RENDER_SPLIT="a,b[,c[,d]]" chooses another split (tiles per pass out of every a + b + ..). */
 int rt_render(rt_context* ctx, const float** out);
 
 /* Render into caller-provided DEVICE memory (same element layout) on a caller-provided HIP stream (hipStream_t passed

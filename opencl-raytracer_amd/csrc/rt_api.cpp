@@ -37,6 +37,7 @@ struct StopWatch {
 };
 
 constexpr uint32_t kTimingSlots = 256;
+constexpr uint32_t kMaxPasses = 4;  // of rt_render's frame (render_in_passes)
 
 }  // namespace
 
@@ -69,17 +70,16 @@ struct rt_context {
 
     uint64_t tile_rays = 0;
     uint32_t rank = 0, world = 1;
+    uint32_t span = 1;      // consecutive ranks one launch stands for (> 1 only inside render_in_passes)
     uint64_t n_local = 0;
 
     void* d_out = nullptr;  // context-owned device framebuffer
     size_t d_out_bytes = 0;
     void* h_out = nullptr;  // context-owned pinned host framebuffer (Render()'s return value)
     size_t h_out_bytes = 0;
-    // rt_render in two passes (render_in_passes): the second pass's device buffer, the stream the read-backs run on, an event per pass
-    void* d_out2 = nullptr;
-    size_t d_out2_bytes = 0;
+    // rt_render in passes (render_in_passes): the stream the read-backs run on, an event per pass
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_pass[2] = {nullptr, nullptr};
+    hipEvent_t ev_pass[kMaxPasses] = {};
 
     float* aux_t = nullptr;  // caller-owned device buffers for the next render
     int32_t* aux_index = nullptr;
@@ -184,11 +184,16 @@ struct DeviceGuard {
 
 size_t elem_bytes(const rt_context* c) { return c->kernel == RT_KERNEL_HITTEST ? sizeof(float) : 4 * sizeof(float); }
 
-uint64_t local_count(uint64_t n_rays, uint64_t tile_rays, uint32_t rank, uint32_t world) {
+// tiles of the frame that ranks rank .. rank + span - 1 of `world` own (tile t belongs to rank t % world)
+uint64_t local_tiles(uint64_t tiles, uint32_t rank, uint32_t world, uint32_t span) {
+    const uint64_t rest = tiles % world;
+    return (tiles / world) * span + (rest > rank ? std::min<uint64_t>(rest - rank, span) : 0);
+}
+
+uint64_t local_count(uint64_t n_rays, uint64_t tile_rays, uint32_t rank, uint32_t world, uint32_t span = 1) {
     if (world <= 1) return n_rays;
     const uint64_t tiles = (n_rays + tile_rays - 1) / tile_rays;
-    const uint64_t mine = tiles / world + ((tiles % world) > rank ? 1 : 0);
-    return mine * tile_rays;  // the last tile may be ragged: its padding work-items write background
+    return local_tiles(tiles, rank, world, span) * tile_rays;  // the last tile may be ragged: its padding work-items write background
 }
 
 // ObjectData[] (320 B AoS, as uploaded by the reference) -> hot traversal stream + cold shading records
@@ -542,6 +547,7 @@ int do_launch(rt_context* c, void* d_out, hipStream_t stream, bool count) {
     p.n_rays = c->n_rays;
     p.n_local = c->n_local;
     p.tile_rays = c->tile_rays ? c->tile_rays : 1;
+    p.run_rays = p.tile_rays * c->span;
     p.rank = c->rank;
     p.world = c->world;
     p.pinhole = c->pinhole ? 1u : 0u;
@@ -1825,60 +1831,83 @@ int rt_render_device(rt_context* c, void* d_out, void* hip_stream) {
     return do_launch(c, d_out, static_cast<hipStream_t>(hip_stream), false);
 }
 
-// The synchronous Render() of a LARGE frame, in two passes: the frame is cut into interleaved row-tiles exactly as for two GPUs
-// (rt_set_shard's partition), pass 0 renders the even tiles, pass 1 the odd ones, and pass 0's tiles travel to the pinned host
-// frame - one strided device-to-host copy on a stream of its own - WHILE pass 1 renders. The blocking read-back of 268 MB
-// (OpenCLRaytracer.cpp:94) is 4.9 ms behind an 11.8 ms cfg4 render; half of it now hides. MEASURED before it was built, with two
-// whole contexts on one GPU (tools/ab/multi_wall.py): 16.87 -> 15.45 ms; four contexts: 18.07 (every pass pays its own drains).
-// Only for frames of the large-scene path with >= 4 M rays that the caller has not sharded himself; RT_RENDER_PASSES=1 switches
-// it off. The pixels are the one-pass frame's, bit for bit (a shard is the same arithmetic on a subset of the rays).
+// The synchronous Render() of a LARGE frame, in passes: the frame is cut into interleaved 16-row tiles as for several GPUs
+// (rt_set_shard's partition; a pass stands for consecutive ranks - RenderParams::run_rays), pass 0 renders three tiles of every
+// four, pass 1 the fourth, and pass 0's tiles travel to the pinned host frame - one strided device-to-host copy on a stream of its
+// own - WHILE pass 1 renders; only the last quarter's copy is left behind the kernels. The blocking read-back of 268 MB
+// (OpenCLRaytracer.cpp:94) is 4.9 ms behind an 11.4 ms cfg4 render. Measured, cfg4 (tools/ab/render_split.py,
+// profiles/r04_experiments/render_split*.txt): one pass 16.5 ms, "1,1" (round 4's first form) 14.8, "3,1" 13.55, "2,1" 13.9,
+// "5,2,1" 13.8, "7,1" 15.1 - an unequal split wins because a small pass renders less efficiently than a large one (a quarter of the
+// frame takes 3.5 ms, not 2.85) while the copy it hides is proportional to the pass before it: 3/4 of the copy (3.7 ms) fits behind
+// the last quarter's render. Only for frames of the large-scene path with >= 4 M rays that the caller has not sharded himself;
+// RT_RENDER_PASSES=1 switches it off, RT_RENDER_SPLIT="a,b,.." chooses another split. The pixels are the one-pass frame's, bit for
+// bit (a shard is the same arithmetic on a subset of the rays).
 static int render_in_passes(rt_context* c, const float** out) {
-    constexpr uint32_t K = 2;
+    // the split: spans of consecutive ranks of a world of their sum ("3,1": three tiles of every four, then the fourth)
+    uint32_t spans[kMaxPasses] = {3, 1, 0, 0}, K = 2, world = 0;
+    if (const char* env = std::getenv("RT_RENDER_SPLIT")) {
+        K = 0;
+        for (const char* q = env; *q && K < kMaxPasses;) {
+            const long v = std::strtol(q, const_cast<char**>(&q), 10);
+            if (v <= 0 || v > 64) { K = 0; break; }
+            spans[K++] = (uint32_t)v;
+            if (*q == ',') ++q;
+        }
+        if (K == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "RT_RENDER_SPLIT: up to 4 comma-separated spans of 1..64 tiles");
+    }
+    for (uint32_t k = 0; k < K; ++k) world += spans[k];
     const uint64_t n_rays = c->n_rays;
     const uint64_t tile_rays = (c->pinhole && c->width) ? 16ull * c->width : 65536ull;
     const uint64_t tiles = (n_rays + tile_rays - 1) / tile_rays;
     const size_t elem = elem_bytes(c), tile_bytes = (size_t)tile_rays * elem;
-    const size_t host_bytes = (size_t)tiles * tile_bytes;  // whole tiles: the ragged last one is padded behind the frame's end
-    if (host_bytes > c->h_out_bytes) {
+    const size_t frame_bytes = (size_t)tiles * tile_bytes;  // whole tiles: the ragged last one is padded behind the frame's end
+    if (frame_bytes > c->h_out_bytes) {
         if (c->h_out) (void)hipHostFree(c->h_out);
         c->h_out = nullptr;
         c->h_out_bytes = 0;
-        RT_HIP(c, hipHostMalloc(&c->h_out, host_bytes, hipHostMallocDefault));
-        c->h_out_bytes = host_bytes;
+        RT_HIP(c, hipHostMalloc(&c->h_out, frame_bytes, hipHostMallocDefault));
+        c->h_out_bytes = frame_bytes;
+    }
+    if (frame_bytes > c->d_out_bytes) {  // the passes' outputs one behind the other
+        if (c->d_out) (void)hipFree(c->d_out);
+        c->d_out = nullptr;
+        c->d_out_bytes = 0;
+        RT_HIP(c, hipMalloc(&c->d_out, frame_bytes));
+        c->d_out_bytes = frame_bytes;
     }
     if (!c->copy_stream) RT_HIP(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     for (uint32_t k = 0; k < K; ++k)
         if (!c->ev_pass[k]) RT_HIP(c, hipEventCreateWithFlags(&c->ev_pass[k], hipEventDisableTiming));
     int rc = RT_OK;
-    for (uint32_t k = 0; k < K && rc == RT_OK; ++k) {
+    size_t at = 0;        // this pass's output within d_out
+    uint32_t rank = 0;    // its first rank
+    const uint64_t groups = tiles / world, rest = tiles % world;
+    for (uint32_t k = 0; k < K && rc == RT_OK; rank += spans[k], ++k) {
         c->tile_rays = tile_rays;
-        c->rank = k;
-        c->world = K;
-        c->n_local = local_count(n_rays, tile_rays, k, K);
-        const size_t need = (size_t)c->n_local * elem;
-        void** buf = k ? &c->d_out2 : &c->d_out;
-        size_t* have = k ? &c->d_out2_bytes : &c->d_out_bytes;
-        if (need > *have) {
-            if (*buf) (void)hipFree(*buf);
-            *buf = nullptr;
-            *have = 0;
-            const hipError_t e = hipMalloc(buf, need ? need : 16);
-            if (e != hipSuccess) { rc = fail_hip(c, e, "hipMalloc (pass buffer)"); break; }
-            *have = need;
-        }
-        rc = do_launch(c, *buf, c->stream, false);
+        c->rank = rank;
+        c->world = world;
+        c->span = spans[k];
+        c->n_local = local_count(n_rays, tile_rays, rank, world, spans[k]);
+        char* buf = static_cast<char*>(c->d_out) + at;
+        const size_t run_bytes = (size_t)spans[k] * tile_bytes;
+        at += (size_t)c->n_local * elem;
+        if (c->n_local == 0) continue;
+        rc = do_launch(c, buf, c->stream, false);
         if (rc != RT_OK) break;
-        const uint64_t mine = tiles / K + ((tiles % K) > k ? 1 : 0);
         hipError_t e = hipEventRecord(c->ev_pass[k], c->stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->copy_stream, c->ev_pass[k], 0);
-        if (e == hipSuccess && mine)  // tile j of this pass is tile j * K + k of the frame
-            e = hipMemcpy2DAsync(static_cast<char*>(c->h_out) + (size_t)k * tile_bytes, (size_t)K * tile_bytes, *buf, tile_bytes, tile_bytes, (size_t)mine,
-                                 hipMemcpyDeviceToHost, c->copy_stream);
+        char* dst = static_cast<char*>(c->h_out) + (size_t)rank * tile_bytes;
+        if (e == hipSuccess && groups)  // run j of this pass is tiles j * world + rank ... of the frame
+            e = hipMemcpy2DAsync(dst, (size_t)world * tile_bytes, buf, run_bytes, run_bytes, (size_t)groups, hipMemcpyDeviceToHost, c->copy_stream);
+        if (e == hipSuccess && rest > rank)  // the short run of the frame's last, incomplete group of tiles
+            e = hipMemcpyAsync(dst + (size_t)groups * world * tile_bytes, buf + (size_t)groups * run_bytes,
+                               (size_t)std::min<uint64_t>(rest - rank, spans[k]) * tile_bytes, hipMemcpyDeviceToHost, c->copy_stream);
         if (e != hipSuccess) rc = fail_hip(c, e, "read-back of a pass");
     }
     c->tile_rays = 0;
     c->rank = 0;
     c->world = 1;
+    c->span = 1;
     c->n_local = n_rays;
     hipError_t e = hipStreamSynchronize(c->stream);
     const hipError_t e2 = hipStreamSynchronize(c->copy_stream);  // Render() is synchronous (OpenCLRaytracer.cpp:94)
@@ -2035,7 +2064,6 @@ void rt_destroy(rt_context* c) {
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_rays) (void)hipFree(c->d_rays);
     if (c->d_out) (void)hipFree(c->d_out);
-    if (c->d_out2) (void)hipFree(c->d_out2);
     if (c->h_out) (void)hipHostFree(c->h_out);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     for (hipEvent_t ev : c->ev_pass) if (ev) (void)hipEventDestroy(ev);

@@ -12,6 +12,7 @@ struct RenderParams {
     uint64_t n_rays;                  // rays of the whole frame
     uint64_t n_local;                 // work-items of this launch (this rank's share)
     uint64_t tile_rays;               // shard tile length in rays
+    uint64_t run_rays;                // consecutive rays of the frame a launch covers per `world` tiles: tile_rays x the ranks it stands for (1: a shard)
     uint32_t rank, world;
     uint32_t pinhole;                 // generate the reference's pinhole grid in-kernel
     uint32_t width;

@@ -79,9 +79,9 @@ __global__ __launch_bounds__(256) void render_pixels(const RenderParams p) {
             active = local < p.n_local;
             g = local;
             if (p.world > 1u) {
-                const uint64_t tile = (uint64_t)local / p.tile_rays;
-                const uint64_t off = (uint64_t)local - tile * p.tile_rays;
-                g = (tile * p.world + p.rank) * p.tile_rays + off;
+                const uint64_t run = (uint64_t)local / p.run_rays;
+                const uint64_t off = (uint64_t)local - run * p.run_rays;
+                g = (run * p.world + p.rank) * p.tile_rays + off;
             }
             if (p.pinhole) {
                 const uint32_t gi = (uint32_t)g;

@@ -249,8 +249,8 @@ __global__ __launch_bounds__(kResumeThreads) void wf_begin(const WfParams wk) {
 __device__ __forceinline__ uint64_t global_ray_of(const RenderParams& p, uint64_t i) {
     const uint64_t px = pixel_of(p, i);
     if (p.world <= 1u) return px;
-    const uint64_t tile = px / p.tile_rays;
-    return (tile * p.world + p.rank) * p.tile_rays + (px - tile * p.tile_rays);
+    const uint64_t run = px / p.run_rays;  // (a shard: run_rays == tile_rays; a pass of rt_render may stand for several consecutive ranks)
+    return (run * p.world + p.rank) * p.tile_rays + (px - run * p.run_rays);
 }
 __device__ __forceinline__ Ray primary_ray(const RenderParams& p, uint64_t g) {
     Ray ray;
@@ -3018,7 +3018,9 @@ static hipError_t run_wavefront(WfParams w, WavefrontBuffers& buf, hipStream_t s
     const bool use_grid = w.grid.enabled && !w.rp.scene.literal;
     // padding work-items exist only in the ragged last tile of a sharded frame: they must not be traced (their global ray
     // does not exist), so such frames go through wf_begin, which leaves them out of the first queue
-    const bool padded = w.rp.world > 1u && (n % w.rp.tile_rays != 0u || ((n / w.rp.tile_rays - 1u) * w.rp.world + w.rp.rank + 1u) * w.rp.tile_rays > w.rp.n_rays);
+    // (work-item -> ray is monotonic, so the last work-item decides; n is a whole number of tiles, the last run may be a short one)
+    const uint64_t last_run = n ? (n - 1u) / w.rp.run_rays : 0u;
+    const bool padded = w.rp.world > 1u && n > 0u && (last_run * w.rp.world + w.rp.rank) * w.rp.tile_rays + (n - last_run * w.rp.run_rays) > w.rp.n_rays;
     static const bool always_begin = std::getenv("RT_WF_ALWAYS_BEGIN") != nullptr;  // measurement knob
     const bool identity = !padded && !always_begin && n > 0;
     if (identity) {

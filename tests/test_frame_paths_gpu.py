@@ -91,14 +91,17 @@ def test_routes_on_a_shard_with_a_ragged_last_tile(monkeypatch):
         assert np.array_equal(frames[name].view(np.uint32), frames["rounds"].view(np.uint32)), name
 
 
-@pytest.mark.parametrize("mode", ["camera", "ray_buffer"])
-def test_render_in_two_passes_is_the_one_pass_frame(monkeypatch, mode):
-    """rt_render of a large frame renders the even and the odd row-tiles one after the other and copies the first half to the
-    host while the second renders (rt_api.cpp: render_in_passes; frames of >= 4 M rays, forced here with RT_RENDER_PASSES=2):
-    same pixels as the one-pass Render(), ragged last tile included, call after call."""
+@pytest.mark.parametrize("mode,H,split", [("camera", 104, None), ("ray_buffer", 104, None), ("camera", 200, None), ("camera", 104, "1,1"),
+                                          ("camera", 200, "5,2,1"), ("camera", 312, "2,1,1,3"), ("ray_buffer", 1000, "2,1")])
+def test_render_in_two_passes_is_the_one_pass_frame(monkeypatch, mode, H, split):
+    """rt_render of a large frame renders three row-tiles of every four, then the fourth, and copies the first pass to the host
+    while the second renders (rt_api.cpp: render_in_passes; frames of >= 4 M rays, forced here with RT_RENDER_PASSES=2; other
+    splits through RT_RENDER_SPLIT): same pixels as the one-pass Render(), short last group of tiles and ragged last tile
+    included, call after call."""
     from opencl_raytracer_amd import synthetic
     objs, lights = synthetic.spheres_and_lights(900, 4)
-    W, H = 168, 104   # 6.5 tiles of 16 rows
+    W = 168           # H = 104: 6.5 tiles of 16 rows; 200: 12.5; 312: 19.5; the ray buffer's tiles are 65 536 rays (1000 rows: 2.6 tiles)
+    if split: monkeypatch.setenv("RT_RENDER_SPLIT", split)
     z = float(camera.camera_z(H))
     make = (lambda: hip(objs, lights, None, 3, camera=(W, H, z))) if mode == "camera" else (lambda: hip(objs, lights, camera.primary_rays(W, H), 3, raygen=False))
     monkeypatch.setenv("RT_RENDER_PASSES", "1")

@@ -3,7 +3,7 @@
 usage: python tools/ab/share8_caps.py"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-for cc, ca in ((None, None), (4096, 2048), (3072, 2048), (4096, 1024), (3072, 1024), (2048, 2048), (6144, 2048), (4096, 4096)):
+for cc, ca in ((None, None), (4096, 2048), (5120, 2048), (5120, 1536), (4096, 1536), (3072, 1536), (5120, 2560), (4096, 2560), (3584, 2048), (4608, 2048)):
     env = dict(os.environ)
     if cc: env["RT_WAVES_CLOSEST"] = str(cc); env["RT_WAVES_ANY"] = str(ca)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools/ab/share_time.py"), "16"], capture_output=True, text=True, env=env)
