@@ -36,6 +36,39 @@ struct StopWatch {
     }
 };
 
+// engineering aid (RT_SETUP_TRACE=1): where the one-time host work goes, lap by lap, on stderr
+struct SetupTrace {
+    const char* who;
+    bool on = std::getenv("RT_SETUP_TRACE") != nullptr;
+    StopWatch sw;
+    explicit SetupTrace(const char* w) : who(w) {}
+    void operator()(const char* what) { if (on) std::fprintf(stderr, "[%s] %-28s %8.2f ms\n", who, what, sw.lap_ms()); }
+};
+
+// One-time host work over independent items (per-tile sorts, per-tile block chains, ...) on several threads: f(begin, end) over
+// [0, n) in contiguous chunks, the calling thread taking the first one. RT_SETUP_THREADS=1 keeps it serial; the results do not
+// depend on the number of threads (every item writes its own outputs).
+template <class F>
+void parallel_for(size_t n, size_t grain, F&& f) {
+    size_t threads = std::thread::hardware_concurrency();
+    if (threads == 0) threads = 1;
+    threads = std::min<size_t>(threads, 16);
+    if (const char* env = std::getenv("RT_SETUP_THREADS")) threads = (size_t)std::max(1, std::atoi(env));
+    threads = std::min(threads, n / std::max<size_t>(grain, 1));
+    if (threads <= 1) { if (n) f((size_t)0, n); return; }
+    const size_t chunk = (n + threads - 1) / threads;
+    std::vector<std::thread> pool;
+    pool.reserve(threads - 1);
+    for (size_t t = 1; t < threads; ++t) {
+        const size_t lo = std::min(n, t * chunk), hi = std::min(n, lo + chunk);
+        if (lo == hi) continue;
+        try { pool.emplace_back([&f, lo, hi] { f(lo, hi); }); }
+        catch (...) { f(lo, hi); }  // (no thread to be had: this chunk on the calling thread)
+    }
+    f((size_t)0, std::min(n, chunk));
+    for (std::thread& th : pool) th.join();
+}
+
 constexpr uint32_t kTimingSlots = 256;
 constexpr uint32_t kMaxPasses = 4;  // of rt_render's frame (render_in_passes)
 
@@ -196,22 +229,27 @@ uint64_t local_count(uint64_t n_rays, uint64_t tile_rays, uint32_t rank, uint32_
     return local_tiles(tiles, rank, world, span) * tile_rays;  // the last tile may be ragged: its padding work-items write background
 }
 
+// traversal stream: objects order[2p] and order[2p+1] (no order: 2p, 2p+1) interleaved entry by entry (rows x,y,z of mvInverse)
+void pack_pairs(const rt_object_data* objs, const uint32_t* order, uint32_t n, std::vector<rt::HotPair>& pairs) {
+    pairs.assign((n + 1) / 2, rt::HotPair{});
+    for (uint32_t i = 0; i < n; ++i) {
+        rt::HotPair& hp = pairs[i / 2];
+        const rt_object_data& o = objs[order ? order[i] : i];
+        const float* m = o.mvInverse;
+        const int half = (int)(i & 1u);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 4; ++c) hp.m[4 * r + c][half] = m[4 * c + r];
+        (half ? hp.type_b : hp.type_a) = o.type;
+    }
+    if (n & 1u) pairs[n / 2].type_b = 0xffffffffu;  // odd count: the missing partner can never be hit
+}
+
 // ObjectData[] (320 B AoS, as uploaded by the reference) -> hot traversal stream + cold shading records
 void repack_objects(const rt_object_data* objs, uint32_t n, std::vector<rt::HotPair>& pairs,
                     std::vector<rt::HotObject>& hot, std::vector<rt::ColdObject>& cold) {
     hot.resize(n);
     cold.resize(n);
-    // traversal stream: objects 2p and 2p+1 interleaved entry by entry (rows x,y,z of mvInverse)
-    pairs.assign((n + 1) / 2, rt::HotPair{});
-    for (uint32_t i = 0; i < n; ++i) {
-        rt::HotPair& hp = pairs[i / 2];
-        const float* m = objs[i].mvInverse;
-        const int half = (int)(i & 1u);
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 4; ++c) hp.m[4 * r + c][half] = m[4 * c + r];
-        (half ? hp.type_b : hp.type_a) = objs[i].type;
-    }
-    if (n & 1u) pairs[n / 2].type_b = 0xffffffffu;  // odd count: the missing partner can never be hit
+    pack_pairs(objs, nullptr, n, pairs);
     for (uint32_t i = 0; i < n; ++i) {
         const rt_object_data& o = objs[i];
         const float* m = o.mvInverse;
@@ -994,6 +1032,7 @@ int build_walk_blocks(rt_context* c, uint32_t n, const std::vector<Bound>& sph, 
 
 // Conservative uniform grid for the large-scene trace kernels (rt_grid.h explains the margins).
 int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
+    SetupTrace lap("grid");
     c->grid = rt::GridDesc{};
     // The grid reasons about ONE line in view space per ray. That needs w = 1 starts, affine instances (checked at
     // upload) and direction.w = 0: with a non-zero direction.w the reference adds every object's own translation
@@ -1049,6 +1088,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
             cell *= 0.7;
         }
     }
+    lap("bounds + cell size");
     // Radii (rt_grid.h derives the bound): with u = 2^-24, a ray that starts `dist` from the centre c of an object
     // with bounding radius R and condition number kappa can only be accepted by the reference's fp32 test if its
     // line passes c within
@@ -1124,6 +1164,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     const size_t n_cells = (size_t)dim[0] * dim[1] * dim[2];
     std::vector<uint32_t> start(n_cells + 1, 0);
     size_t total = 0;
+    lap("radii + box");
     // (object, cell) pairs: counted in 64 bits against the budget as the first pass goes, and an object's BOX of cells
     // is checked before its cells are visited - many large overlapping objects must neither wrap the 32-bit prefix
     // sums nor cost billions of iterations before the grid is given up
@@ -1261,6 +1302,7 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     g.always = c->d_grid_always;
     g.n_always = (uint32_t)always.size();
     g.has_triangles = c->has_triangles ? 1u : 0u;
+    lap("cell lists + uploads");
     {   // first-cell rule (rt_grid.h: entered_inside; RT_WALK_FIRST_CELL): the ball it uses must stay inside every object's
         // registration radius by 1e-3 cell (DDA) + the rule's own fp32 rounding (~1e-6 of the largest coordinate)
         double worst = 0.0;  // max over objects of |pre-test radius| - registration radius (normally about -0.01 cell)
@@ -1306,6 +1348,7 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
     const float* lp = lights[li].position;
     if (!(lp[3] != 0.f) || !std::isfinite(lp[0] + lp[1] + lp[2])) return RT_OK;  // directional (or garbage): no centre of projection
     const double L[3] = {lp[0], lp[1], lp[2]};
+    SetupTrace lap("light tiles");
     const uint32_t n = c->n_objs;
     const double inf = std::numeric_limits<double>::infinity();
     // The fp32 shadow ray - start fl(P + 0.01 n), direction fl(L - P) - misses the exact line through the light by about
@@ -1370,6 +1413,7 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
         U0 = std::min(U0, rc.u0); U1 = std::max(U1, rc.u1); V0 = std::min(V0, rc.v0); V1 = std::max(V1, rc.v1);
     }
     if (!(U1 > U0) || !(V1 > V0) || !std::isfinite(U0 + U1 + V0 + V1)) return RT_OK;
+    lap("axis + rectangles");
     // tile count: ~1.6 sqrt(n) per axis, halved while the lists would hold more than 24 entries per object
     double tile_factor = 1.6;
     if (const char* env = std::getenv("RT_LT_TILE_FACTOR")) {  // tuning knob (results do not depend on it)
@@ -1425,6 +1469,7 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
         }
     }
     std::vector<uint2> ranges((size_t)T * T);
+    lap("count + fill");
     for (size_t k = 0; k < ranges.size(); ++k) ranges[k] = make_uint2(start[k], start[k + 1] - start[k]);
     // a tile's entries ordered by how far from the light the object starts: a ray's list ends at the first one that starts
     // beyond its own origin (an occluder's hit point lies between origin and light, within the registration radius of its centre)
@@ -1436,23 +1481,32 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
         const double d = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) - (r0 + kPad);
         key[i] = std::nextafter((float)(d * (1.0 - 1e-6)), -std::numeric_limits<float>::infinity());
     }
-    for (size_t t = 0; t < ranges.size(); ++t)
-        std::sort(entries.begin() + start[t], entries.begin() + start[t + 1], [&](uint32_t a, uint32_t b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
-    std::vector<float4> recs(2 * (size_t)total);
-    for (size_t k = 0; k < (size_t)total; ++k) {
-        const uint32_t i = entries[k];
-        float id_bits;
-        std::memcpy(&id_bits, &i, 4);
-        recs[2 * k] = make_float4((float)c->h_grid_spheres[4 * i], (float)c->h_grid_spheres[4 * i + 1], (float)c->h_grid_spheres[4 * i + 2], c->h_grid_pre[i]);
-        recs[2 * k + 1] = make_float4(key[i], id_bits, 0.f, 0.f);
-    }
-    RT_HIP(c, hipMalloc((void**)&c->d_lt_range, sizeof(uint2) * ranges.size()));
-    RT_HIP(c, hipMalloc((void**)&c->d_lt_records, sizeof(float4) * (recs.size() + 2)));
-    RT_HIP(c, hipMemcpy(c->d_lt_range, ranges.data(), sizeof(uint2) * ranges.size(), hipMemcpyHostToDevice));
-    if (total) RT_HIP(c, hipMemcpy(c->d_lt_records, recs.data(), sizeof(float4) * recs.size(), hipMemcpyHostToDevice));
+    parallel_for(ranges.size(), 4096, [&](size_t t0, size_t t1) {
+        for (size_t t = t0; t < t1; ++t)
+            std::sort(entries.begin() + start[t], entries.begin() + start[t + 1], [&](uint32_t a, uint32_t b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
+    });
+    lap("keys + per-tile sorts");
+    // The lists as RECORDS (tile_range + two float4 per entry) are what the kernels read where the block form below is not
+    // built; with blocks they are never touched, and 56 MB of them (cfg4) are neither made nor uploaded.
+    std::vector<float4> recs;
+    auto upload_records = [&]() -> int {
+        recs.resize(2 * (size_t)total);
+        for (size_t k = 0; k < (size_t)total; ++k) {
+            const uint32_t i = entries[k];
+            float id_bits;
+            std::memcpy(&id_bits, &i, 4);
+            recs[2 * k] = make_float4((float)c->h_grid_spheres[4 * i], (float)c->h_grid_spheres[4 * i + 1], (float)c->h_grid_spheres[4 * i + 2], c->h_grid_pre[i]);
+            recs[2 * k + 1] = make_float4(key[i], id_bits, 0.f, 0.f);
+        }
+        RT_HIP(c, hipMalloc((void**)&c->d_lt_range, sizeof(uint2) * ranges.size()));
+        RT_HIP(c, hipMalloc((void**)&c->d_lt_records, sizeof(float4) * (recs.size() + 2)));
+        RT_HIP(c, hipMemcpy(c->d_lt_range, ranges.data(), sizeof(uint2) * ranges.size(), hipMemcpyHostToDevice));
+        if (total) RT_HIP(c, hipMemcpy(c->d_lt_records, recs.data(), sizeof(float4) * recs.size(), hipMemcpyHostToDevice));
+        c->light_tiles.tile_range = c->d_lt_range;
+        c->light_tiles.records = c->d_lt_records;
+        return RT_OK;
+    };
     rt::LightTiles& lt = c->light_tiles;
-    lt.tile_range = c->d_lt_range;
-    lt.records = c->d_lt_records;
     lt.lx = lp[0]; lt.ly = lp[1]; lt.lz = lp[2];
     lt.u0 = u0f; lt.v0 = v0f; lt.inv_du = inv_du; lt.inv_dv = inv_dv;
     lt.tiles_u = T; lt.tiles_v = T;
@@ -1506,33 +1560,44 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
         ok = ok && rstepf > 0.f && std::isfinite(rstepf) && std::isfinite(kstepf) && rt::light_tile_blocks_fit(n_lt_blocks);
         if (ok) {
             const size_t heads = ranges.size();
-            std::vector<uint32_t> blk(8 * heads, 0u), bid(4 * heads, c->n_objs);
-            const uint32_t empty_hi = 0xff000000u;
-            for (size_t b = 0; b < heads; ++b) blk[8 * b + 3] = blk[8 * b + 5] = blk[8 * b + 7] = empty_hi;
-            for (size_t t = 0; t < heads; ++t) {
-                size_t at = t;
-                for (uint32_t j = 0; j < ranges[t].y; ++j) {
-                    const uint32_t slot = j % 3u;
-                    if (j && slot == 0u) {  // the chain goes on in a new block behind the heads
-                        const size_t nb = blk.size() / 8;
-                        blk.resize(blk.size() + 8, 0u);
-                        bid.resize(bid.size() + 4, c->n_objs);
-                        blk[8 * nb + 3] = blk[8 * nb + 5] = blk[8 * nb + 7] = empty_hi;
-                        blk[8 * at] = (uint32_t)nb;
-                        at = nb;
-                    }
-                    const uint32_t i = entries[(size_t)ranges[t].x + j];
-                    uint32_t r8 = (uint32_t)std::ceil(wq[i] / (double)rstepf);
-                    while (r8 < 255u && (double)((float)r8 * rstepf) < wq[i]) ++r8;  // (the device's own product must not fall short)
-                    if (r8 > 255u) r8 = 255u;
-                    double kk = std::floor(std::max((double)key[i], 0.0) / (double)kstepf * (1.0 - 1e-6));
-                    uint32_t k8 = (uint32_t)std::min(255.0, std::max(0.0, kk));
-                    while (k8 > 0u && (double)((float)k8 * kstepf) > (double)key[i]) --k8;  // (rounded DOWN: an entry may only look nearer to the light)
-                    blk[8 * at + 2 + 2 * slot] = (uint32_t)q[3 * i] | ((uint32_t)q[3 * i + 1] << 16);
-                    blk[8 * at + 3 + 2 * slot] = (uint32_t)q[3 * i + 2] | (r8 << 16) | (k8 << 24);
-                    bid[4 * at + slot] = i;
-                }
+            // what an entry's two words hold depends on its object alone: the centre on the lattice, the radius rounded UP and
+            // the key rounded DOWN to their 8-bit steps - once per object, not once per entry (1.75 M entries for 100 k objects)
+            std::vector<uint2> packed(n, make_uint2(0u, 0u));
+            for (uint32_t i = 0; i < n; ++i) {
+                if (!(rect[i].u1 >= rect[i].u0)) continue;
+                uint32_t r8 = (uint32_t)std::ceil(wq[i] / (double)rstepf);
+                while (r8 < 255u && (double)((float)r8 * rstepf) < wq[i]) ++r8;  // (the device's own product must not fall short)
+                if (r8 > 255u) r8 = 255u;
+                double kk = std::floor(std::max((double)key[i], 0.0) / (double)kstepf * (1.0 - 1e-6));
+                uint32_t k8 = (uint32_t)std::min(255.0, std::max(0.0, kk));
+                while (k8 > 0u && (double)((float)k8 * kstepf) > (double)key[i]) --k8;  // (rounded DOWN: an entry may only look nearer to the light)
+                packed[i] = make_uint2((uint32_t)q[3 * i] | ((uint32_t)q[3 * i + 1] << 16), (uint32_t)q[3 * i + 2] | (r8 << 16) | (k8 << 24));
             }
+            // tile t's head is block t; the further blocks of the chains follow the heads in tile order
+            std::vector<uint32_t> chain_at(heads + 1, 0u);
+            for (size_t t = 0; t < heads; ++t) chain_at[t + 1] = chain_at[t] + (ranges[t].y > 3u ? (ranges[t].y - 1u) / 3u : 0u);
+            const size_t n_blocks = heads + chain_at[heads];
+            std::vector<uint32_t> blk(8 * n_blocks, 0u), bid(4 * n_blocks, c->n_objs);
+            const uint32_t empty_hi = 0xff000000u;
+            parallel_for(n_blocks, 1u << 16, [&](size_t b0, size_t b1) {
+                for (size_t b = b0; b < b1; ++b) blk[8 * b + 3] = blk[8 * b + 5] = blk[8 * b + 7] = empty_hi;
+            });
+            parallel_for(heads, 4096, [&](size_t t0, size_t t1) {
+                for (size_t t = t0; t < t1; ++t) {
+                    size_t at = t, next = heads + chain_at[t];
+                    for (uint32_t j = 0; j < ranges[t].y; ++j) {
+                        const uint32_t slot = j % 3u;
+                        if (j && slot == 0u) {  // the chain goes on in its next block behind the heads
+                            blk[8 * at] = (uint32_t)next;
+                            at = next++;
+                        }
+                        const uint32_t i = entries[(size_t)ranges[t].x + j];
+                        blk[8 * at + 2 + 2 * slot] = packed[i].x;
+                        blk[8 * at + 3 + 2 * slot] = packed[i].y;
+                        bid[4 * at + slot] = i;
+                    }
+                }
+            });
             RT_HIP(c, hipMalloc((void**)&c->d_lt_blocks, sizeof(uint32_t) * blk.size()));
             RT_HIP(c, hipMalloc((void**)&c->d_lt_block_ids, sizeof(uint32_t) * bid.size()));
             RT_HIP(c, hipMemcpy(c->d_lt_blocks, blk.data(), sizeof(uint32_t) * blk.size(), hipMemcpyHostToDevice));
@@ -1542,10 +1607,16 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
             lt.lat_lox = lof[0]; lt.lat_loy = lof[1]; lt.lat_loz = lof[2];
             lt.lat_step = stepf; lt.rstep = rstepf; lt.kstep = kstepf;
             lt.blocks_enabled = 1u;
+            lap("blocks + uploads");
             if (std::getenv("RT_WALK_STATS"))
                 std::fprintf(stderr, "[light tiles] %u x %u tiles, %llu entries, %zu blocks (%zu behind the heads), lattice step %g, radius step %g, key step %g\n",
                              T, T, (unsigned long long)total, blk.size() / 8, blk.size() / 8 - heads, (double)stepf, (double)rstepf, (double)kstepf);
         }
+    }
+    if (!lt.blocks_enabled) {
+        const int rc = upload_records();
+        if (rc != RT_OK) return rc;
+        lap("records + uploads");
     }
     if (!c->h_walk.empty() && total && !lt.blocks_enabled) {  // (no blocks - RT_NO_LT_BLOCKS: the lists as records of the unified walk, each tile's chained to its end)
         const uint64_t base = c->h_walk.size() / 2;
@@ -1652,12 +1723,8 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
             std::vector<double> size(n_objs);
             for (uint32_t i = 0; i < n_objs; ++i) { order[i] = i; size[i] = size_proxy(od[i]); }
             std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return size[a] > size[b]; });
-            std::vector<rt_object_data> sorted(n_objs);
-            for (uint32_t i = 0; i < n_objs; ++i) sorted[i] = od[order[i]];
             std::vector<rt::HotPair> spairs;
-            std::vector<rt::HotObject> shot;
-            std::vector<rt::ColdObject> scold;
-            repack_objects(sorted.data(), n_objs, spairs, shot, scold);
+            pack_pairs(od, order.data(), n_objs, spairs);
             RT_TRY(hipMemcpy(c->d_shadow_pairs, spairs.data(), sizeof(rt::HotPair) * spairs.size(), hipMemcpyHostToDevice));
         }
         lap("pair streams (sort, upload)");

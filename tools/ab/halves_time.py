@@ -13,7 +13,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 desc, objs, lights, W, H, kernel, depth = bench.load_workload(wl)
 z = float(camera.camera_z(H))
-for parts in (1, 2, 3, 4):
+for parts in tuple(int(x) for x in os.environ.get("HALVES_PARTS", "1,2,3,4").split(",")):
     rts, bufs, streams = [], [], []
     for r in range(parts):
         rt = HIPRaytracer(objs, lights, None, depth, kernel=kernel, camera=(W, H, z))
