@@ -1481,7 +1481,7 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
         const double d = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]) - (r0 + kPad);
         key[i] = std::nextafter((float)(d * (1.0 - 1e-6)), -std::numeric_limits<float>::infinity());
     }
-    parallel_for(ranges.size(), 4096, [&](size_t t0, size_t t1) {
+    parallel_for(ranges.size(), 1024, [&](size_t t0, size_t t1) {
         for (size_t t = t0; t < t1; ++t)
             std::sort(entries.begin() + start[t], entries.begin() + start[t + 1], [&](uint32_t a, uint32_t b) { return key[a] < key[b] || (key[a] == key[b] && a < b); });
     });
@@ -1579,10 +1579,10 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
             const size_t n_blocks = heads + chain_at[heads];
             std::vector<uint32_t> blk(8 * n_blocks, 0u), bid(4 * n_blocks, c->n_objs);
             const uint32_t empty_hi = 0xff000000u;
-            parallel_for(n_blocks, 1u << 16, [&](size_t b0, size_t b1) {
+            parallel_for(n_blocks, 1u << 12, [&](size_t b0, size_t b1) {
                 for (size_t b = b0; b < b1; ++b) blk[8 * b + 3] = blk[8 * b + 5] = blk[8 * b + 7] = empty_hi;
             });
-            parallel_for(heads, 4096, [&](size_t t0, size_t t1) {
+            parallel_for(heads, 1024, [&](size_t t0, size_t t1) {
                 for (size_t t = t0; t < t1; ++t) {
                     size_t at = t, next = heads + chain_at[t];
                     for (uint32_t j = 0; j < ranges[t].y; ++j) {

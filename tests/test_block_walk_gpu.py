@@ -100,6 +100,30 @@ def test_three_closest_hit_walks_agree_on_a_reflecting_frame(monkeypatch):
         assert frames["blocks_rays"] == frames[name + "_rays"], name
 
 
+def test_light_tiles_as_records_and_serial_setup_give_the_same_frame(monkeypatch):
+    """The last light's tiles exist in two forms: three-candidate blocks (default; the record form is then not even built) and
+    records (RT_NO_LT_BLOCKS; also what a table beyond 2^24 blocks falls back to). rt_create builds the blocks on several
+    threads (RT_SETUP_THREADS=1: on one). Same frame and same ray counts every way, and as brute force."""
+    rng = np.random.default_rng(23)
+    objs, lights = _scene(rng, 2500, 4, 40, lights=3)
+    W, H = 192, 128
+    z = float(camera.camera_z(H))
+    frames = {}
+    for name, env in (("blocks", {}), ("serial", {"RT_SETUP_THREADS": "1"}), ("threads3", {"RT_SETUP_THREADS": "3"}), ("records", {"RT_NO_LT_BLOCKS": "1"}),
+                      ("brute", None)):
+        for k in ("RT_SETUP_THREADS", "RT_NO_LT_BLOCKS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in (env or {}).items():
+            monkeypatch.setenv(k, v)
+        with hip(objs, lights, None, 3, camera=(W, H, z), grid=env is not None) as rt:
+            frames[name] = rt.Render()
+            st = rt.count_rays()
+            frames[name + "_rays"] = (st.rays_reference, st.rays_traced)
+    for name in ("serial", "threads3", "records", "brute"):
+        assert np.array_equal(frames["blocks"].view(np.uint32), frames[name].view(np.uint32)), name
+        assert frames["blocks_rays"] == frames[name + "_rays"], name
+
+
 def test_meshes_block_walk_equals_the_round2_walk(monkeypatch):
     """Triangles (the extension) have no brute-force path to compare with; their block walk - triangle branch in the exact tests,
     empty-space steps from the block headers, light tiles in block form - is held against round 2's walk (RT_NO_TRI_BLOCKS), which
