@@ -47,9 +47,10 @@ def _rays(rng, n, kind):
     if kind == "inside":       # origins all over the cloud, every direction
         rays["start"][:, :3] = rng.uniform([-30, -30, -90], [30, 30, -25], (n, 3))
         rays["direction"][:, :3] = rng.normal(size=(n, 3)) * rng.uniform(0.01, 50.0, (n, 1))
-    elif kind == "far":        # origins thousands of units away, aimed at the cloud
+    elif kind in ("far", "outside"):  # origins thousands of units away - or ("outside") ten to a thousand cells - aimed at the cloud
         o = rng.normal(size=(n, 3))
-        o = o / np.linalg.norm(o, axis=1, keepdims=True) * rng.uniform(2.0e3, 4.0e4, (n, 1)) + np.array([0, 0, -55.0])
+        dist = rng.uniform(2.0e3, 4.0e4, (n, 1)) if kind == "far" else np.exp(rng.uniform(np.log(60.0), np.log(3.0e3), (n, 1)))
+        o = o / np.linalg.norm(o, axis=1, keepdims=True) * dist + np.array([0, 0, -55.0])
         tgt = rng.uniform([-28, -28, -88], [28, 28, -27], (n, 3))
         rays["start"][:, :3] = o
         rays["direction"][:, :3] = (tgt - o) * rng.uniform(0.5, 2.0, (n, 1))
@@ -62,9 +63,9 @@ def _rays(rng, n, kind):
     return rays
 
 
-@pytest.mark.parametrize("kind", ["inside", "far", "scaled"])
+@pytest.mark.parametrize("kind", ["inside", "far", "outside", "scaled"])
 def test_block_walk_equals_brute_force_on_awkward_scenes_and_rays(kind):
-    rng = np.random.default_rng({"inside": 5, "far": 6, "scaled": 7}[kind])
+    rng = np.random.default_rng({"inside": 5, "far": 6, "scaled": 7, "outside": 8}[kind])
     objs, lights = _scene(rng, 2500, 9, 60)
     rays = _rays(rng, 6000, kind)
     with np.errstate(all="ignore"):

@@ -9,6 +9,8 @@ SWEEP = [{}] + [{"RT_WAVES_ANY": v} for v in ("1024", "2048", "3072", "6144", "8
         [{"RT_LT_TILE_FACTOR": v} for v in ("1.2", "2.0", "2.5")] + \
         [{"RT_WF_FINISH_THRESHOLD": v} for v in ("32768", "65536", "262144")] + \
         [{"RT_GRID_CELLS_PER_OBJECT": v} for v in ("2", "4")] + [{}]
+if os.environ.get("SWEEP_VAR"):  # SWEEP_VAR=NAME SWEEP_VALUES=a,b,c: one knob, the default before and after
+    SWEEP = [{}] + [{os.environ["SWEEP_VAR"]: v} for v in os.environ.get("SWEEP_VALUES", "").split(",") if v] + [{}]
 for env_add in SWEEP:
     env = dict(os.environ); env.update(env_add)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-extra", "--steps", "5", "--warmup", "2"] + sys.argv[1:],
