@@ -17,6 +17,7 @@
 #include <limits>
 #include <new>
 #include <string>
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -232,15 +233,18 @@ uint64_t local_count(uint64_t n_rays, uint64_t tile_rays, uint32_t rank, uint32_
 // traversal stream: objects order[2p] and order[2p+1] (no order: 2p, 2p+1) interleaved entry by entry (rows x,y,z of mvInverse)
 void pack_pairs(const rt_object_data* objs, const uint32_t* order, uint32_t n, std::vector<rt::HotPair>& pairs) {
     pairs.assign((n + 1) / 2, rt::HotPair{});
-    for (uint32_t i = 0; i < n; ++i) {
-        rt::HotPair& hp = pairs[i / 2];
-        const rt_object_data& o = objs[order ? order[i] : i];
-        const float* m = o.mvInverse;
-        const int half = (int)(i & 1u);
-        for (int r = 0; r < 3; ++r)
-            for (int c = 0; c < 4; ++c) hp.m[4 * r + c][half] = m[4 * c + r];
-        (half ? hp.type_b : hp.type_a) = o.type;
-    }
+    parallel_for(pairs.size(), 8192, [&](size_t p0, size_t p1) {
+        for (size_t p = p0; p < p1; ++p)
+            for (uint32_t i = (uint32_t)(2 * p); i < n && i < 2 * p + 2; ++i) {
+                rt::HotPair& hp = pairs[p];
+                const rt_object_data& o = objs[order ? order[i] : i];
+                const float* m = o.mvInverse;
+                const int half = (int)(i & 1u);
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 4; ++c) hp.m[4 * r + c][half] = m[4 * c + r];
+                (half ? hp.type_b : hp.type_a) = o.type;
+            }
+    });
     if (n & 1u) pairs[n / 2].type_b = 0xffffffffu;  // odd count: the missing partner can never be hit
 }
 
@@ -250,7 +254,8 @@ void repack_objects(const rt_object_data* objs, uint32_t n, std::vector<rt::HotP
     hot.resize(n);
     cold.resize(n);
     pack_pairs(objs, nullptr, n, pairs);
-    for (uint32_t i = 0; i < n; ++i) {
+    parallel_for(n, 16384, [&](size_t i0, size_t i1) {
+    for (size_t i = i0; i < i1; ++i) {
         const rt_object_data& o = objs[i];
         const float* m = o.mvInverse;
         rt::HotObject& h = hot[i];
@@ -279,6 +284,7 @@ void repack_objects(const rt_object_data* objs, uint32_t n, std::vector<rt::HotP
         std::memcpy(&type_bits, &o.type, 4);
         c.spec_type = make_float4(o.mat.specular[0], o.mat.specular[1], o.mat.specular[2], type_bits);
     }
+    });
 }
 
 // View-space bounding sphere of what the traversal tests for object o: { x : |A x + b| <= r0 } with A, b the
@@ -831,6 +837,7 @@ int upload_walk_records(rt_context* c) {
 int build_walk_blocks(rt_context* c, uint32_t n, const std::vector<Bound>& sph, const std::vector<double>& rg, double cell_fine,
                       const double glo[3], const double ghi[3], double K2) {
     c->blocks = rt::BlockGrid{};
+    SetupTrace lap("block grid");
     if (std::getenv("RT_NO_WALK3") || c->h_grid_pre.size() != n) return RT_OK;  // (measurement knob: the record walk)
     double factor = 1.67;
     if (const char* env = std::getenv("RT_WALK_BLOCK_FACTOR")) {  // tuning knob (results do not depend on it)
@@ -906,6 +913,7 @@ int build_walk_blocks(rt_context* c, uint32_t n, const std::vector<Bound>& sph, 
             }
         }
     }
+    lap("registration");
     // blocks
     struct Enc { uint32_t word; uint32_t id; int s; };
     std::vector<uint32_t> blocks((size_t)n_cells * 8, 0u), ids((size_t)n_cells * 8, c->n_objs);
@@ -972,6 +980,7 @@ int build_walk_blocks(rt_context* c, uint32_t n, const std::vector<Bound>& sph, 
                 }
             }
     if ((uint64_t)blocks.size() * 4ull >= 0xf0000000ull) return RT_OK;
+    lap("encoding");
     {   // Empty cells say how many FURTHER steps of a walk are sure to stay in empty cells: the Chebyshev distance to the nearest
         // occupied cell minus one (a walk moves by one face per step), two-pass chamfer over the 26-neighbourhood of the padded
         // array, capped at 63 - in the six header bits the chain pointer and the scale leave free (24-26 and 29-31). The walk takes
@@ -1005,10 +1014,12 @@ int build_walk_blocks(rt_context* c, uint32_t n, const std::vector<Bound>& sph, 
             blocks[8 * k] |= ((skip & 7u) << 24) | ((skip >> 3) << 29);
         }
     }
+    lap("empty-space distances");
     RT_HIP(c, hipMalloc((void**)&c->d_walk_blocks, sizeof(uint32_t) * blocks.size()));
     RT_HIP(c, hipMalloc((void**)&c->d_walk_ids, sizeof(uint32_t) * ids.size()));
     RT_HIP(c, hipMemcpy(c->d_walk_blocks, blocks.data(), sizeof(uint32_t) * blocks.size(), hipMemcpyHostToDevice));
     RT_HIP(c, hipMemcpy(c->d_walk_ids, ids.data(), sizeof(uint32_t) * ids.size(), hipMemcpyHostToDevice));
+    lap("uploads");
     rt::BlockGrid& b = c->blocks;
     if (const char* env = std::getenv("RT_BLOCK_SKIPS")) b.take_skips = env[0] != '0' ? 1u : 0u;  // measurement knob
     b.lox = lof[0]; b.loy = lof[1]; b.loz = lof[2];
@@ -1042,8 +1053,8 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
     double lo[3] = {c->origin_lo[0], c->origin_lo[1], c->origin_lo[2]};
     double hi[3] = {c->origin_hi[0], c->origin_hi[1], c->origin_hi[2]};
     const double inf = std::numeric_limits<double>::infinity();
+    parallel_for(n, 8192, [&](size_t i0, size_t i1) { for (size_t i = i0; i < i1; ++i) sph[i] = object_bound(objs[i]); });
     for (uint32_t i = 0; i < n; ++i) {
-        sph[i] = object_bound(objs[i]);
         if (!std::isfinite(sph[i].r)) continue;  // +inf: always-list, -inf: can never be hit
         const double cc[3] = {sph[i].x, sph[i].y, sph[i].z};
         const double pad = sph[i].r * 1.01;
@@ -1211,11 +1222,13 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
             if (pass == 0 && counted > entry_budget) return RT_OK;  // objects too large for this cell size: not worth it
         }
         if (pass == 0) {
+            lap("cell lists: count");
             for (size_t k = 0; k < n_cells; ++k) start[k + 1] += start[k];
             total = start[n_cells];
             // the kernels address these tables with 32-bit byte offsets (table_at)
             if ((uint64_t)total * 16ull >= 0xffffffffull || (uint64_t)n_cells * 32ull >= 0xffffffffull) return RT_OK;
         } else {
+            lap("cell lists: fill");
             RT_HIP(c, hipMalloc((void**)&c->d_grid_entries, sizeof(uint32_t) * (total + 1)));
             RT_HIP(c, hipMalloc((void**)&c->d_grid_always, sizeof(uint32_t) * (always.size() + 1)));
             {   // per entry: the sphere the object was registered with (rounded outwards), for the kernels' pre-test
@@ -1225,14 +1238,18 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
                     c->h_grid_pre[i] = rpre[i] >= 0 ? std::nextafter((float)rpre[i], std::numeric_limits<float>::infinity())
                                                     : std::nextafter((float)rpre[i], -std::numeric_limits<float>::infinity());
                 std::vector<float4> es(total);
-                for (size_t k = 0; k < total; ++k) {
-                    const uint32_t i = entries[k];
-                    es[k] = make_float4((float)sph[i].x, (float)sph[i].y, (float)sph[i].z, c->h_grid_pre[i]);
-                }
+                parallel_for(total, 1u << 16, [&](size_t k0, size_t k1) {
+                    for (size_t k = k0; k < k1; ++k) {
+                        const uint32_t i = entries[k];
+                        es[k] = make_float4((float)sph[i].x, (float)sph[i].y, (float)sph[i].z, c->h_grid_pre[i]);
+                    }
+                });
                 RT_HIP(c, hipMalloc((void**)&c->d_grid_entry_sphere, sizeof(float4) * (total + 1)));
                 if (total) RT_HIP(c, hipMemcpy(c->d_grid_entry_sphere, es.data(), sizeof(float4) * total, hipMemcpyHostToDevice));
                 std::vector<uint2> ranges(n_cells);
-                for (size_t k = 0; k < n_cells; ++k) ranges[k] = make_uint2(start[k], start[k + 1] - start[k]);
+                parallel_for(n_cells, 1u << 18, [&](size_t k0, size_t k1) {
+                    for (size_t k = k0; k < k1; ++k) ranges[k] = make_uint2(start[k], start[k + 1] - start[k]);
+                });
                 // Empty cells carry, in the unused offset word, how many FURTHER steps of a walk are sure to land in
                 // empty cells too: the Chebyshev distance to the nearest occupied cell minus one (a walk moves by one
                 // face per step), from a two-pass chamfer over the 26-neighbourhood, capped at 255. The grid walk
@@ -1264,8 +1281,10 @@ int build_grid(rt_context* c, const rt_object_data* objs, uint32_t n) {
                     for (size_t k = 0; k < n_cells; ++k)
                         if (ranges[k].y == 0) ranges[k].x = dist[k] > 1 ? (uint32_t)dist[k] - 1u : 0u;
                 } else {
-                    for (size_t k = 0; k < n_cells; ++k)
-                        if (ranges[k].y == 0) ranges[k].x = 0u;
+                    parallel_for(n_cells, 1u << 18, [&](size_t k0, size_t k1) {
+                        for (size_t k = k0; k < k1; ++k)
+                            if (ranges[k].y == 0) ranges[k].x = 0u;
+                    });
                 }
                 RT_HIP(c, hipMalloc((void**)&c->d_grid_cell_range, sizeof(uint2) * n_cells));
                 RT_HIP(c, hipMemcpy(c->d_grid_cell_range, ranges.data(), sizeof(uint2) * n_cells, hipMemcpyHostToDevice));
@@ -1401,15 +1420,23 @@ int build_light_tiles(rt_context* c, const rt_light* lights) {
         hi += 1e-5 * (1.0 + std::fabs(hi));
         return true;
     };
+    std::atomic<bool> no_span{false};  // an object without a usable tangent: no light tiles for this scene
+    parallel_for(n, 8192, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1 && !no_span.load(std::memory_order_relaxed); ++i) {
+            const double r0 = c->h_grid_spheres[4 * i + 3];
+            if (!(r0 >= 0) || r0 == inf) continue;  // can never be hit
+            const double r = r0 + kPad;
+            const double q[3] = {c->h_grid_spheres[4 * i] - L[0], c->h_grid_spheres[4 * i + 1] - L[1], c->h_grid_spheres[4 * i + 2] - L[2]};
+            const double qx = q[ax], qy = q[ay], qz = szn * q[az];
+            Rect rc;
+            if (!span(qx, qz, r, rc.u0, rc.u1) || !span(qy, qz, r, rc.v0, rc.v1)) { no_span.store(true, std::memory_order_relaxed); break; }
+            rect[i] = rc;
+        }
+    });
+    if (no_span.load()) return RT_OK;
     for (uint32_t i = 0; i < n; ++i) {
-        const double r0 = c->h_grid_spheres[4 * i + 3];
-        if (!(r0 >= 0) || r0 == inf) continue;  // can never be hit
-        const double r = r0 + kPad;
-        const double q[3] = {c->h_grid_spheres[4 * i] - L[0], c->h_grid_spheres[4 * i + 1] - L[1], c->h_grid_spheres[4 * i + 2] - L[2]};
-        const double qx = q[ax], qy = q[ay], qz = szn * q[az];
-        Rect rc;
-        if (!span(qx, qz, r, rc.u0, rc.u1) || !span(qy, qz, r, rc.v0, rc.v1)) return RT_OK;
-        rect[i] = rc;
+        const Rect& rc = rect[i];
+        if (!(rc.u1 >= rc.u0)) continue;
         U0 = std::min(U0, rc.u0); U1 = std::max(U1, rc.u1); V0 = std::min(V0, rc.v0); V1 = std::max(V1, rc.v1);
     }
     if (!(U1 > U0) || !(V1 > V0) || !std::isfinite(U0 + U1 + V0 + V1)) return RT_OK;
@@ -1750,13 +1777,15 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
         {   // matrix rows of both directions + absorption side by side (ObjectRecord)
             std::vector<rt::ObjectRecord> rec((size_t)n_objs + 1);
             std::memset(rec.data(), 0, sizeof(rt::ObjectRecord) * rec.size());
-            for (uint32_t i = 0; i < n_objs; ++i) {
-                rec[i].inv_row[0] = hot[i].row0; rec[i].inv_row[1] = hot[i].row1; rec[i].inv_row[2] = hot[i].row2;
-                rec[i].type = hot[i].type;
-                rec[i].pad0 = hot[i].pad[0];
-                rec[i].absorption = cold[i].amb_absorb.w;
-                for (int r = 0; r < 3; ++r) rec[i].mv_row[r] = cold[i].mv_row[r];
-            }
+            parallel_for(n_objs, 16384, [&](size_t i0, size_t i1) {
+                for (size_t i = i0; i < i1; ++i) {
+                    rec[i].inv_row[0] = hot[i].row0; rec[i].inv_row[1] = hot[i].row1; rec[i].inv_row[2] = hot[i].row2;
+                    rec[i].type = hot[i].type;
+                    rec[i].pad0 = hot[i].pad[0];
+                    rec[i].absorption = cold[i].amb_absorb.w;
+                    for (int r = 0; r < 3; ++r) rec[i].mv_row[r] = cold[i].mv_row[r];
+                }
+            });
             rec[n_objs].type = 0xffffffffu;
             RT_TRY(hipMalloc((void**)&c->d_objrec, sizeof(rt::ObjectRecord) * rec.size()));
             RT_TRY(hipMemcpy(c->d_objrec, rec.data(), sizeof(rt::ObjectRecord) * rec.size(), hipMemcpyHostToDevice));
@@ -1782,9 +1811,15 @@ int rt_create(rt_context** out_ctx, const void* objs, uint32_t n_objs, const voi
     // a scale of 0, garbage) makes the reference's result depend on the ORDER its loop meets the objects in - a NaN
     // time overwrites and is overwritten. The exact eliminations (any-hit shadow rays on a size-sorted stream, the
     // grid) assume finite times, so such scenes are rendered the literal way: every ray, every object, in order.
-    for (uint32_t i = 0; i < n_objs && !(c->flags & RT_FLAG_LITERAL); ++i) {
-        const rt_object_data& o = static_cast<const rt_object_data*>(objs)[i];
-        if (o.type <= 1u && !std::isfinite(object_bound(o).r)) { c->flags |= RT_FLAG_LITERAL; c->forced_literal = true; }
+    if (!(c->flags & RT_FLAG_LITERAL)) {
+        std::atomic<bool> degenerate{false};
+        parallel_for(n_objs, 8192, [&](size_t i0, size_t i1) {
+            for (size_t i = i0; i < i1 && !degenerate.load(std::memory_order_relaxed); ++i) {
+                const rt_object_data& o = static_cast<const rt_object_data*>(objs)[i];
+                if (o.type <= 1u && !std::isfinite(object_bound(o).r)) degenerate.store(true, std::memory_order_relaxed);
+            }
+        });
+        if (degenerate.load()) { c->flags |= RT_FLAG_LITERAL; c->forced_literal = true; }
     }
     lap("instance checks");
     c->base_flags = c->flags;
