@@ -698,29 +698,37 @@ int build_screen_tiles(rt_context* c, hipStream_t stream, uint32_t col_shift) {
     constexpr size_t kMaxGlobal = 64;
     const uint64_t budget = 256ull * n + 4096ull;
     uint64_t total = 0;
+    // every object's tile rectangle (the expensive part: screen_rect), on several threads; what depends on the order - the budget,
+    // the global list, the counts - in a second, serial sweep
+    parallel_for(n, 8192, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
+            const double r = c->h_grid_spheres[4 * i + 3];
+            Range& q = rng[i];
+            q.x0 = 0; q.x1 = -1; q.y0 = 0; q.y1 = -1;
+            if (!(r >= 0) || r == inf) continue;  // never hit / always-list (handled by the kernel)
+            const float4 rect = screen_rect(Sphere{c->h_grid_spheres[4 * i], c->h_grid_spheres[4 * i + 1], c->h_grid_spheres[4 * i + 2], r}, (double)c->z);
+            if (!(rect.x <= rect.y) || !(rect.z <= rect.w)) continue;  // empty: behind the camera
+            // direction x = col - W/2  ->  col range; direction y = (H - row) - H/2  ->  row range
+            const double c0 = (double)rect.x + half_w, c1 = (double)rect.y + half_w;
+            const double r0 = H - half_h - (double)rect.w, r1 = H - half_h - (double)rect.z;
+            const double cx0 = std::max(0.0, std::floor(c0)), cx1 = std::min((double)c->width - 1, std::ceil(c1));
+            const double ry0 = std::max(0.0, std::floor(r0)), ry1 = std::min((double)c->height - 1, std::ceil(r1));
+            if (cx0 > cx1 || ry0 > ry1) continue;
+            q.x0 = (int)(cx0 / tile_w); q.x1 = (int)(cx1 / tile_w); q.y0 = (int)(ry0 / 8); q.y1 = (int)(ry1 / 8);
+        }
+    });
     for (uint32_t i = 0; i < n; ++i) {
-        const double r = c->h_grid_spheres[4 * i + 3];
         Range& q = rng[i];
-        q.x0 = 0; q.x1 = -1; q.y0 = 0; q.y1 = -1;
-        if (!(r >= 0) || r == inf) continue;  // never hit / always-list (handled by the kernel)
-        const float4 rect = screen_rect(Sphere{c->h_grid_spheres[4 * i], c->h_grid_spheres[4 * i + 1], c->h_grid_spheres[4 * i + 2], r}, (double)c->z);
-        if (!(rect.x <= rect.y) || !(rect.z <= rect.w)) continue;  // empty: behind the camera
-        // direction x = col - W/2  ->  col range; direction y = (H - row) - H/2  ->  row range
-        const double c0 = (double)rect.x + half_w, c1 = (double)rect.y + half_w;
-        const double r0 = H - half_h - (double)rect.w, r1 = H - half_h - (double)rect.z;
-        const double cx0 = std::max(0.0, std::floor(c0)), cx1 = std::min((double)c->width - 1, std::ceil(c1));
-        const double ry0 = std::max(0.0, std::floor(r0)), ry1 = std::min((double)c->height - 1, std::ceil(r1));
-        if (cx0 > cx1 || ry0 > ry1) continue;
-        const int x0 = (int)(cx0 / tile_w), x1 = (int)(cx1 / tile_w), y0 = (int)(ry0 / 8), y1 = (int)(ry1 / 8);
-        const uint64_t covered = (uint64_t)(x1 - x0 + 1) * (uint64_t)(y1 - y0 + 1);
+        if (q.x1 < q.x0 || q.y1 < q.y0) continue;
+        const uint64_t covered = (uint64_t)(q.x1 - q.x0 + 1) * (uint64_t)(q.y1 - q.y0 + 1);
         if (covered == (uint64_t)n_tiles && n_tiles > 1) {  // the whole screen
             if (global.size() >= kMaxGlobal) return RT_OK;
             global.push_back(i);
+            q.x0 = 0; q.x1 = -1; q.y0 = 0; q.y1 = -1;
             continue;
         }
         total += covered;
         if (total > budget) return RT_OK;  // objects cover most of the screen: the grid walk is the better tool
-        q.x0 = x0; q.x1 = x1; q.y0 = y0; q.y1 = y1;
         for (int y = q.y0; y <= q.y1; ++y)
             for (int x = q.x0; x <= q.x1; ++x) start[(size_t)y * tx + x + 1] += 1;
     }
@@ -916,69 +924,90 @@ int build_walk_blocks(rt_context* c, uint32_t n, const std::vector<Bound>& sph, 
     lap("registration");
     // blocks
     struct Enc { uint32_t word; uint32_t id; int s; };
-    std::vector<uint32_t> blocks((size_t)n_cells * 8, 0u), ids((size_t)n_cells * 8, c->n_objs);
-    uint64_t hist[5] = {0, 0, 0, 0, 0}, chain_blocks = 0;
-    std::vector<Enc> enc;
-    for (uint64_t wz = 0; wz < wn[2]; ++wz)
-        for (uint64_t wy = 0; wy < wn[1]; ++wy)
-            for (uint64_t wx = 0; wx < wn[0]; ++wx) {
-                const size_t k = (size_t)((wz * wn[1] + wy) * wn[0] + wx);
-                const uint32_t cnt = start[k + 1] - start[k];
-                if (cnt == 0) continue;
-                const float Cdev[3] = {std::fmaf((float)wx, cellf, c0[0]), std::fmaf((float)wy, cellf, c0[1]), std::fmaf((float)wz, cellf, c0[2])};
-                enc.clear();
-                for (uint32_t j = 0; j < cnt; ++j) {
-                    const uint32_t i = entries[start[k] + j];
-                    const double w = std::fabs((double)c->h_grid_pre[i]);
-                    const double cc[3] = {sph[i].x, sph[i].y, sph[i].z};
-                    Enc e{(255u << 24) | (128u << 16) | (128u << 8) | 128u, i, 3};  // the whole cell and then some: 255 steps of cell / 16 around its centre
-                    bool found = false;
-                    for (int sc = 0; sc < 4 && !found; ++sc) {
-                        const double inv = (double)inv_step * std::ldexp(1.0, -sc), step = 1.0 / inv;
-                        double d2 = 0;
-                        int q[3];
-                        bool ok = true;
-                        for (int a = 0; a < 3; ++a) {
-                            const double u = (cc[a] - (double)Cdev[a]) * inv + 128.0;
-                            q[a] = (int)std::floor(u + 0.5);
-                            if (q[a] < 0 || q[a] > 255) ok = false;
-                            d2 += (u - q[a]) * (u - q[a]);
-                        }
-                        if (!ok) continue;
-                        // centre error in view-space units + the rounding of the device's transform of the ray origin
-                        const double delta = std::sqrt(d2) * step + 1.5 * 5.97e-8 * (2.0 * Dmax + 128.0 * step);
-                        const double w2 = (w + delta) * (w + delta) + 2.0 * delta * sq_alpha0 * Dmax + alpha0 * (2.0 * delta * Dmax + delta * delta);
-                        const double r_lat = std::sqrt(w2) * (1.0 + 1e-6) * inv + 1e-3;
-                        const int r = (int)std::ceil(r_lat);
-                        if (r > 255) continue;
-                        e = Enc{((uint32_t)r << 24) | ((uint32_t)q[2] << 16) | ((uint32_t)q[1] << 8) | (uint32_t)q[0], i, sc};
-                        found = true;
+    // Two sweeps over the cells, each on several threads: (1) every entry of a cell encoded on the finest of the four lattices that
+    // holds it, the cell's entries ordered by lattice (stable), the blocks its chain needs counted; (2) - after a prefix sum that
+    // gives every chain the indices it would get if the cells were laid out one after the other - the blocks written. The table is
+    // the serial builder's, byte for byte.
+    std::vector<Enc> encs((size_t)total);
+    std::vector<uint32_t> chain_at((size_t)n_cells + 1, 0u);  // blocks behind the head, per cell; then their prefix sum
+    std::atomic<uint64_t> hist_sum[5];
+    for (auto& h : hist_sum) h.store(0);
+    parallel_for((size_t)n_cells, 4096, [&](size_t k0, size_t k1) {
+        uint64_t hist_local[5] = {0, 0, 0, 0, 0};
+        for (size_t k = k0; k < k1; ++k) {
+            const uint32_t cnt = start[k + 1] - start[k];
+            if (cnt == 0) continue;
+            const uint64_t wx = (uint64_t)k % wn[0], wy = ((uint64_t)k / wn[0]) % wn[1], wz = (uint64_t)k / (wn[0] * wn[1]);
+            const float Cdev[3] = {std::fmaf((float)wx, cellf, c0[0]), std::fmaf((float)wy, cellf, c0[1]), std::fmaf((float)wz, cellf, c0[2])};
+            Enc* enc = encs.data() + start[k];
+            for (uint32_t j = 0; j < cnt; ++j) {
+                const uint32_t i = entries[start[k] + j];
+                const double w = std::fabs((double)c->h_grid_pre[i]);
+                const double cc[3] = {sph[i].x, sph[i].y, sph[i].z};
+                Enc e{(255u << 24) | (128u << 16) | (128u << 8) | 128u, i, 3};  // the whole cell and then some: 255 steps of cell / 16 around its centre
+                bool found = false;
+                for (int sc = 0; sc < 4 && !found; ++sc) {
+                    const double inv = (double)inv_step * std::ldexp(1.0, -sc), step = 1.0 / inv;
+                    double d2 = 0;
+                    int q[3];
+                    bool ok = true;
+                    for (int a = 0; a < 3; ++a) {
+                        const double u = (cc[a] - (double)Cdev[a]) * inv + 128.0;
+                        q[a] = (int)std::floor(u + 0.5);
+                        if (q[a] < 0 || q[a] > 255) ok = false;
+                        d2 += (u - q[a]) * (u - q[a]);
                     }
-                    hist[found ? e.s : 4] += 1;
-                    enc.push_back(e);
+                    if (!ok) continue;
+                    // centre error in view-space units + the rounding of the device's transform of the ray origin
+                    const double delta = std::sqrt(d2) * step + 1.5 * 5.97e-8 * (2.0 * Dmax + 128.0 * step);
+                    const double w2 = (w + delta) * (w + delta) + 2.0 * delta * sq_alpha0 * Dmax + alpha0 * (2.0 * delta * Dmax + delta * delta);
+                    const double r_lat = std::sqrt(w2) * (1.0 + 1e-6) * inv + 1e-3;
+                    const int r = (int)std::ceil(r_lat);
+                    if (r > 255) continue;
+                    e = Enc{((uint32_t)r << 24) | ((uint32_t)q[2] << 16) | ((uint32_t)q[1] << 8) | (uint32_t)q[0], i, sc};
+                    found = true;
                 }
-                std::stable_sort(enc.begin(), enc.end(), [](const Enc& a, const Enc& b) { return a.s < b.s; });
-                size_t at = k, pos = 0;
-                while (pos < enc.size()) {
-                    const int sc = enc[pos].s;
-                    uint32_t m = 0;
-                    while (m < rt::kBlockEntries && pos < enc.size() && enc[pos].s == sc) {
-                        blocks[at * 8 + 1 + m] = enc[pos].word;
-                        ids[at * 8 + m] = enc[pos].id;
-                        ++m; ++pos;
-                    }
-                    uint32_t next = 0;
-                    if (pos < enc.size()) {
-                        next = (uint32_t)(blocks.size() / 8);
-                        if (next >= (1u << 24)) return RT_OK;
-                        blocks.resize(blocks.size() + 8, 0u);
-                        ids.resize(ids.size() + 8, c->n_objs);
-                        ++chain_blocks;
-                    }
-                    blocks[at * 8] = next | ((uint32_t)sc << 27);
-                    at = next;
-                }
+                hist_local[found ? e.s : 4] += 1;
+                enc[j] = e;
             }
+            std::stable_sort(enc, enc + cnt, [](const Enc& a, const Enc& b) { return a.s < b.s; });
+            uint32_t n_blocks = 0;
+            for (uint32_t pos = 0; pos < cnt; ++n_blocks) {
+                const int sc = enc[pos].s;
+                uint32_t m = 0;
+                while (m < rt::kBlockEntries && pos < cnt && enc[pos].s == sc) { ++m; ++pos; }
+            }
+            chain_at[k + 1] = n_blocks - 1u;
+        }
+        for (int h = 0; h < 5; ++h) hist_sum[h].fetch_add(hist_local[h], std::memory_order_relaxed);
+    });
+    uint64_t hist[5], chain_blocks = 0;
+    for (int h = 0; h < 5; ++h) hist[h] = hist_sum[h].load();
+    for (size_t k = 0; k < (size_t)n_cells; ++k) { chain_blocks += chain_at[k + 1]; chain_at[k + 1] = (uint32_t)chain_blocks; }  // (< total <= 2^31)
+    if (chain_blocks != 0 && n_cells + chain_blocks > (1ull << 24)) return RT_OK;  // block indices are 24 bits in a header
+    const size_t n_blocks_all = (size_t)(n_cells + chain_blocks);
+    std::vector<uint32_t> blocks(n_blocks_all * 8, 0u), ids(n_blocks_all * 8, c->n_objs);
+    parallel_for((size_t)n_cells, 4096, [&](size_t k0, size_t k1) {
+        for (size_t k = k0; k < k1; ++k) {
+            const uint32_t cnt = start[k + 1] - start[k];
+            if (cnt == 0) continue;
+            const Enc* enc = encs.data() + start[k];
+            size_t at = k, next_free = (size_t)n_cells + chain_at[k];
+            uint32_t pos = 0;
+            while (pos < cnt) {
+                const int sc = enc[pos].s;
+                uint32_t m = 0;
+                while (m < rt::kBlockEntries && pos < cnt && enc[pos].s == sc) {
+                    blocks[at * 8 + 1 + m] = enc[pos].word;
+                    ids[at * 8 + m] = enc[pos].id;
+                    ++m; ++pos;
+                }
+                const uint32_t next = pos < cnt ? (uint32_t)next_free++ : 0u;
+                blocks[at * 8] = next | ((uint32_t)sc << 27);
+                at = next;
+            }
+        }
+    });
     if ((uint64_t)blocks.size() * 4ull >= 0xf0000000ull) return RT_OK;
     lap("encoding");
     {   // Empty cells say how many FURTHER steps of a walk are sure to stay in empty cells: the Chebyshev distance to the nearest
